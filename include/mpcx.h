@@ -1,0 +1,140 @@
+/*
+ * mpcx -- batched iterative linear MPC for AMD MI355X (gfx950).
+ *
+ * C ABI of libmpcx.so.  The reference project (pure Python) has no FFI of its
+ * own: its boundary is a handful of Python functions called once per robot per
+ * control tick.  Each entry point below is the batched form of one of them and
+ * cites the function it stands in for; the Python modules in
+ * model_predictive_control_amd/ keep the reference's names and signatures and
+ * forward here.
+ *
+ * Conventions
+ *  - every data pointer is a DEVICE pointer (HIP), row-major, one record per
+ *    instance:  x0 [B][3];  xref / xbar / x_out [B][3][T+1];  controls
+ *    [B][NU][T] with dual-steer rows v_f, delta_f, v_r, delta_r
+ *    (mpc_dsr.py:186-190, mpc.py:99-102);
+ *  - `stream` is a hipStream_t (NULL = the default stream); calls are
+ *    asynchronous on it and return after the launches are queued;
+ *  - return value 0 = ok, negative = error (MPCX_E_*); mpcx_last_error() gives
+ *    the message for the calling thread; no exception crosses this boundary;
+ *  - per-instance outcome goes to status_out (MPCX_ST_*).  The reference
+ *    signals failure by printing "Error: Cannot solve mpc.." and returning
+ *    Nones (mpc_diff_drive.py:209-215); the Python layer maps any status other
+ *    than OK / INACCURATE to that.
+ */
+#ifndef MPCX_H
+#define MPCX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCX_ABI_VERSION 1
+
+#define MPCX_MODEL_DIFF_DRIVE 0 /* unicycle, NU = 2 (mpc_diff_drive.py:19-21) */
+#define MPCX_MODEL_DSR 1        /* dual-steer "general bicycle", NU = 4 (mpc_dsr.py:20-22) */
+
+/* equalities between control rows -> two free controls per stage */
+#define MPCX_EQ_NONE 0        /* diff-drive                                           */
+#define MPCX_EQ_ACKERMANN 1   /* u0 = u2, u1 = -u3        (mpc_dsr.py:242-243)        */
+#define MPCX_EQ_CRAB 2        /* u0 = u2, u1 =  u3        (mpc_dsr.py:310-311)        */
+#define MPCX_EQ_FIXED_STEER 3 /* u1 = u3 = steer_fixed    (mpc_dsr.py:369-370)        */
+
+#define MPCX_ST_OK 0          /* solved to tolerance                                   */
+#define MPCX_ST_INACCURATE 1  /* solved to the loose tolerance only (the reference also
+                                 accepts OPTIMAL_INACCURATE, mpc_diff_drive.py:202)    */
+#define MPCX_ST_INFEASIBLE 2  /* empty constraint set (first-step window vs box)       */
+#define MPCX_ST_NONFINITE 3   /* NaN/Inf in the inputs                                 */
+#define MPCX_ST_FAILED 4      /* iteration limit without reaching the loose tolerance  */
+
+#define MPCX_E_ARG (-1)
+#define MPCX_E_UNSUPPORTED (-2)
+#define MPCX_E_HIP (-3)
+#define MPCX_E_NOMEM (-4)
+
+#define MPCX_MAX_T 64
+
+/* One row of the variant table: everything that distinguishes the reference's QPs
+ * (mpc_diff_drive.py:170-217; mpc_dsr.py:201-395; mpc_sim.py:312-508; mpc.py:117-187). */
+typedef struct mpcx_variant {
+    int32_t model;      /* MPCX_MODEL_*                                                   */
+    int32_t nu;         /* 2 or 4                                                         */
+    int32_t T;          /* horizon (1..MPCX_MAX_T)                                        */
+    int32_t eq_mode;    /* MPCX_EQ_*                                                      */
+    int32_t chain;      /* >1: mpc_sim.py:295-308's chained solves per call               */
+    int32_t pad_;
+    double dt;          /* time tick                                                      */
+    double wb;          /* wheel base                                                     */
+    double R[4];        /* input cost diagonal                                            */
+    double Rd[4];       /* input-difference cost diagonal (mpc.py:152-153), else 0        */
+    double Q[3];        /* state cost diagonal, stages 1..T-1                             */
+    double q_growth;    /* stage t uses Q * q_growth^t (mpc_dsr.py:349), else 1           */
+    double Qf[3];       /* terminal state cost diagonal                                   */
+    double umax[4];     /* |u_i| <= umax_i            (+inf = none)                       */
+    double dumax[4];    /* |u_i[t+1]-u_i[t]| <= ...   (+inf = none)                       */
+    double first_step[4]; /* |u_i[0]-uref_i[0]| <= ... (+inf = none)                      */
+    double steer_fixed; /* MPCX_EQ_FIXED_STEER only                                       */
+    double cold_start[4]; /* controls used when there is no previous solution            */
+} mpcx_variant;
+
+int mpcx_abi_version(void);
+const char *mpcx_last_error(void);
+
+/* Fills *out with one of the reference's variants: "diff_drive", "dsr_ackermann",
+ * "dsr_crab", "dsr_diff", "sim_ackermann", "sim_diff", "sim_crab", "mpc_py". */
+int mpcx_variant_by_name(const char *name, mpcx_variant *out);
+
+/* Bytes of device workspace mpcx_solve_batch / mpcx_linear_mpc_batch need for B
+ * instances of this variant (0 for the register-resident T = 5 path).  The library keeps
+ * one grow-only buffer per device for it; calls that need it are serialised per device. */
+int64_t mpcx_workspace_bytes(const mpcx_variant *v, int64_t B);
+
+/* iterative_linear_mpc_control (mpc_diff_drive.py:142-167, mpc_dsr.py:169-199),
+ * MPC.iterativeLMPC (mpc_sim.py:284-310) and the solve part of
+ * ModelPredictiveControl.start (mpc.py:83-102): cold start if no previous controls,
+ * rollout, T linearisations, one QP (chain QPs when v->chain > 1).
+ *   uprev may be NULL (all cold); has_prev may be NULL (all warm when uprev != NULL).
+ *   iters_out may be NULL. */
+int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const double *xref,
+                     const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,
+                     double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream);
+
+/* linear_mpc_control (mpc_diff_drive.py:170-217), linear_mpc_control_{ackermann,crab,diff}
+ * (mpc_dsr.py:201-395), MPC.doLMPC_* (mpc_sim.py:312-508), controlLaw (mpc.py:117-187):
+ * one QP at the given linearisation point (xbar, uref). */
+int mpcx_linear_mpc_batch(const mpcx_variant *v, int64_t B, const double *xref, const double *xbar,
+                          const double *x0, const double *uref, double *u_out, double *x_out,
+                          double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream);
+
+/* predict_motion (mpc_diff_drive.py:126-139, mpc_dsr.py:125-139, mpc_sim.py:268-282,
+ * mpc.py:385-421): xbar [B][3][T+1] from x0 and the control rows u [B][NU][T]. */
+int mpcx_rollout_batch(const mpcx_variant *v, int64_t B, const double *x0, const double *u,
+                       double *xbar, void *stream);
+
+/* get_linear_model_matrix (mpc_diff_drive.py:220-238, mpc_dsr.py:397-426),
+ * getRobotModelMatrice (mpc_sim.py:132-163, mpc.py:354-383):
+ * theta [B], u [B][NU] -> A [B][3][3], Bm [B][3][NU], C [B][3]. */
+int mpcx_linearize_batch(const mpcx_variant *v, int64_t B, const double *theta, const double *u,
+                         double *A, double *Bm, double *C, void *stream);
+
+/* calc_nearest_index (mpc_diff_drive.py:103-123, mpc_sim.py:510-518) followed by
+ * calc_ref_trajectory (mode 0, param = dl; mpc_diff_drive.py:241-269) or
+ * calc_ref_trajectory2 / getReferenceTrajectory (mode 1, param = n_search_ind;
+ * mpc_diff_drive.py:271-296, mpc_sim.py:520-539).
+ *   state [B][4] = x, y, yaw, vx;  course_id [B] (NULL = course 0);  pind [B];
+ *   course tables cx, cy, cyaw [K][Lmax] with clen [K] valid points each;
+ *   ind_out [B] (-1 = empty search window, where the reference raises);
+ *   mind_out [B] or NULL (signed as in mpc_diff_drive.py:116-121 when sign != 0);
+ *   xref_out [B][3][T+1] or NULL. */
+int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int32_t n_search,
+                           int32_t sign, int64_t B, const double *state, const int32_t *course_id,
+                           const int32_t *pind, const double *cx, const double *cy,
+                           const double *cyaw, const int32_t *clen, int64_t n_courses, int64_t Lmax,
+                           int32_t *ind_out, double *mind_out, double *xref_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCX_H */

@@ -1,0 +1,701 @@
+// Device-side building blocks of the batched iterative linear MPC engine (gfx950).
+//
+// One MPC instance = one lane.  The same templates serve two storage policies:
+//   RegStore<T>  every per-instance array is a local array with compile-time
+//                indices after full unrolling (VGPR/AGPR resident); the
+//                condensed Hessian sits in LDS as [element][lane];
+//   MemStore     runtime horizon; arrays live in a global workspace laid out
+//                [element][instance] so a wavefront's accesses coalesce.
+//
+// Algorithm per instance (float64 throughout):
+//   rollout yaw -> T linearisations -> eliminate states (condensed QP in the 2
+//   free controls per stage) -> primal-dual interior point (Mehrotra
+//   predictor-corrector, strictly feasible start, slacks recomputed from the
+//   iterate) with one Cholesky per iteration -> controls, predicted states,
+//   objective.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mpcx.h"
+
+namespace mpcx {
+
+constexpr int kWave = 64;
+constexpr double kSlackMin = 1e-16;   // floor on a recomputed slack
+constexpr double kMu0 = 0.1;          // initial complementarity s*lambda
+constexpr double kTolD = 1e-9;        // relative stationarity
+constexpr double kTolMu = 1e-12;      // mean complementarity
+constexpr double kLooseD = 1e-6;      // "inaccurate but accepted" thresholds
+constexpr double kLooseMu = 1e-7;
+constexpr double kEtaCap = 0.999;
+constexpr double kMinWidth = 2e-9;    // a first-stage window narrower than this is widened to it
+constexpr double kBig = 1e300;
+
+__device__ __forceinline__ double rcp_raw(double x) { return __builtin_amdgcn_rcp(x); }
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    double e = fma(-(x * r), r, 1.0);
+    r = fma(0.5 * r, e, r);
+    e = fma(-(x * r), r, 1.0);
+    r = fma(0.5 * r, e, r);
+    return r;
+}
+__device__ __forceinline__ bool finite_d(double x) { return fabs(x) <= 1.79769313486231570e308; }
+
+// ------------------------------------------------------------------------------------
+// models
+// ------------------------------------------------------------------------------------
+
+// A = I + (a02 at [0][2], a12 at [1][2]); Bm 3x4 (NU columns used); C[3]; omega = yaw
+// rate of the plant at these controls (what predict_motion integrates).
+// Diff-drive: mpc_diff_drive.py:220-238 and :92-100.
+// Dual steer: mpc_dsr.py:397-426 entry by entry (B[2][0] uses sin(delta_r), B[1][3] has
+// the (sin dr cos th - cos dr sin th) pattern, C multiplies by (delta + theta): these are
+// the reference's formulas, not the analytic Jacobian) and :141-167 for the twist.
+template <int MODEL>
+__device__ __forceinline__ void linearize(const mpcx_variant &v, double th, const double (&u)[4],
+                                          double &a02, double &a12, double (&Bm)[3][4],
+                                          double (&C)[3], double &omega)
+{
+    const double dt = v.dt;
+    double st, ct;
+    sincos(th, &st, &ct);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Bm[r][k] = 0.0;
+    if (MODEL == MPCX_MODEL_DIFF_DRIVE) {
+        const double vr = u[0];
+        a02 = -vr * st * dt;
+        a12 = vr * ct * dt;
+        Bm[0][0] = ct * dt;
+        Bm[1][0] = st * dt;
+        Bm[2][1] = dt;
+        C[0] = vr * st * th * dt;
+        C[1] = -vr * ct * th * dt;
+        C[2] = 0.0;
+        omega = u[1];
+    } else {
+        const double v_f = u[0], d_f = u[1], v_r = u[2], d_r = u[3];
+        double sf, cf, sr, cr;
+        sincos(d_f, &sf, &cf);
+        sincos(d_r, &sr, &cr);
+        const double h = 0.5 * dt, k = 1.0 / v.wb * dt;
+        const double vc = v_f * cf + v_r * cr, vs = v_f * sf + v_r * sr;
+        a02 = -0.5 * dt * vc * st - 0.5 * dt * vs * ct;
+        a12 = 0.5 * dt * vc * ct - 0.5 * dt * vs * st;
+        Bm[0][0] = h * (cf * ct - sf * st);
+        Bm[0][1] = -h * (sf * ct + cf * st) * v_f;
+        Bm[0][2] = h * (cr * ct - sr * st);
+        Bm[0][3] = -h * (sr * ct + cr * st) * v_r;
+        Bm[1][0] = h * (cf * st + sf * ct);
+        Bm[1][1] = -h * (sf * st - cf * ct) * v_f;
+        Bm[1][2] = h * (cr * st + sr * ct);
+        Bm[1][3] = -h * (sr * ct - cr * st) * v_r;
+        Bm[2][0] = k * sr;
+        Bm[2][1] = k * cf * v_f;
+        Bm[2][2] = -k * sr;
+        Bm[2][3] = -k * cr * v_r;
+        const double af = d_f + th, ar = d_r + th;
+        C[0] = h * (v_f * cf * st * af + v_r * cr * st * ar + v_f * sf * ct * af + v_r * sr * ct * ar);
+        C[1] = h * (-v_f * cf * ct * af - v_r * cr * ct * ar + v_f * sf * st * af + v_r * sr * st * ar);
+        C[2] = k * (-cf * d_f * v_f + cr * d_r * v_r);
+        omega = (sf * v_f - sr * v_r) / v.wb;
+    }
+}
+
+// One plant step of predict_motion (mpc_diff_drive.py:92-100; mpc_dsr.py:114-123,141-167).
+template <int MODEL>
+__device__ __forceinline__ void plant_step(const mpcx_variant &v, double &x, double &y, double &yaw,
+                                           const double (&u)[4])
+{
+    double s, c;
+    sincos(yaw, &s, &c);
+    const double dt = v.dt;
+    if (MODEL == MPCX_MODEL_DIFF_DRIVE) {
+        x = x + u[0] * c * dt;
+        y = y + u[0] * s * dt;
+        yaw = yaw + u[1] * dt;
+    } else {
+        double sf, cf, sr, cr;
+        sincos(u[1], &sf, &cf);
+        sincos(u[3], &sr, &cr);
+        const double v1x = cf * u[0], v1y = sf * u[0], v2x = cr * u[2], v2y = sr * u[2];
+        const double vx = 0.5 * (v1x + v2x), vy = 0.5 * (v1y + v2y), w = (v1y - v2y) / v.wb;
+        x = x + vx * c * dt - vy * s * dt;
+        y = y + vx * s * dt + vy * c * dt;
+        yaw = yaw + w * dt;
+    }
+}
+
+// Yaw rate only (the QP needs xbar[2][t] and nothing else of the rollout).
+template <int MODEL>
+__device__ __forceinline__ double yaw_rate(const mpcx_variant &v, const double (&u)[4])
+{
+    if (MODEL == MPCX_MODEL_DIFF_DRIVE) return u[1];
+    return (sin(u[1]) * u[0] - sin(u[3]) * u[2]) / v.wb;
+}
+
+// ------------------------------------------------------------------------------------
+// bounds of the two free controls per stage (uniform parts + per-instance first stage)
+// ------------------------------------------------------------------------------------
+struct FreeBounds {
+    double b[2];     // |w_c| <= b[c] for stages >= 1 (and stage 0 before the window)
+    double rr[2];    // |w_c[t+1] - w_c[t]| <= rr[c]
+    double lo0[2], hi0[2];
+    bool box[2], box0[2], rate[2];   // which of them are finite (uniform over the batch)
+    bool feasible;
+};
+
+__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+
+// uref0: first column of uref (all NU rows; unused rows ignored).
+__device__ __forceinline__ void free_bounds(const mpcx_variant &v, const double (&u0)[4], FreeBounds &fb)
+{
+    const double *um = v.umax, *dm = v.dumax, *fs = v.first_step;
+    double wl[2], wh[2];
+    bool fsfin[2];
+    fb.feasible = true;
+    if (v.eq_mode == MPCX_EQ_NONE) {
+        fb.b[0] = um[0]; fb.b[1] = um[1];
+        fb.rr[0] = dm[0]; fb.rr[1] = dm[1];
+        wl[0] = u0[0] - fs[0]; wh[0] = u0[0] + fs[0];
+        wl[1] = u0[1] - fs[1]; wh[1] = u0[1] + fs[1];
+        fsfin[0] = finite_d(fs[0]); fsfin[1] = finite_d(fs[1]);
+    } else if (v.eq_mode == MPCX_EQ_FIXED_STEER) {
+        fb.b[0] = um[0]; fb.b[1] = um[2];
+        fb.rr[0] = dm[0]; fb.rr[1] = dm[2];
+        wl[0] = u0[0] - fs[0]; wh[0] = u0[0] + fs[0];
+        wl[1] = u0[2] - fs[2]; wh[1] = u0[2] + fs[2];
+        fsfin[0] = finite_d(fs[0]); fsfin[1] = finite_d(fs[2]);
+        if (fabs(v.steer_fixed) > um[1] || fabs(u0[1] - v.steer_fixed) > fs[1]) fb.feasible = false;
+        if (fabs(v.steer_fixed) > um[3] || fabs(u0[3] - v.steer_fixed) > fs[3]) fb.feasible = false;
+    } else {
+        const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
+        fb.b[0] = dmin(um[0], um[2]); fb.b[1] = dmin(um[1], um[3]);
+        fb.rr[0] = dmin(dm[0], dm[2]); fb.rr[1] = dmin(dm[1], dm[3]);
+        wl[0] = dmax(u0[0] - fs[0], u0[2] - fs[2]); wh[0] = dmin(u0[0] + fs[0], u0[2] + fs[2]);
+        wl[1] = dmax(u0[1] - fs[1], sg * u0[3] - fs[3]); wh[1] = dmin(u0[1] + fs[1], sg * u0[3] + fs[3]);
+        fsfin[0] = finite_d(fs[0]) || finite_d(fs[2]);
+        fsfin[1] = finite_d(fs[1]) || finite_d(fs[3]);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        fb.box[c] = finite_d(fb.b[c]);
+        fb.rate[c] = finite_d(fb.rr[c]);
+        fb.box0[c] = fb.box[c] || fsfin[c];
+        fb.lo0[c] = dmax(-fb.b[c], wl[c]);
+        fb.hi0[c] = dmin(fb.b[c], wh[c]);
+        if (!(fb.lo0[c] <= fb.hi0[c])) fb.feasible = false;
+        // a (near) zero-width window has no interior: widen it to kMinWidth, far below the
+        // 1e-3 the controls are compared at
+        if (fb.box0[c] && fb.hi0[c] - fb.lo0[c] < kMinWidth) {
+            const double mid = 0.5 * (fb.lo0[c] + fb.hi0[c]);
+            fb.lo0[c] = mid - 0.5 * kMinWidth;
+            fb.hi0[c] = mid + 0.5 * kMinWidth;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// storage policies
+// ------------------------------------------------------------------------------------
+template <int T_>
+struct RegStore {
+    static constexpr bool kStatic = true;
+    static constexpr int T = T_, N = 2 * T_, NT = N * (N + 1) / 2;
+    double K_[NT];
+    double G_[3 * N], g_[N], w_[N], lamU_[N], lamL_[N], nuU_[N], nuL_[N];
+    double hw_[N], dwa_[N], dw_[N], rinv_[N], isu_[N], isl_[N], iru_[N], irl_[N];
+    double sa02_[T], sa12_[T], sb_[6 * T], sc_[3 * T], theta_[T], uref_[4 * T];
+    double *Hs;   // LDS, [NT][64], already offset by the lane
+    __device__ __forceinline__ int horizon() const { return T; }
+    __device__ __forceinline__ static int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+    __device__ __forceinline__ double &Hacc(int i, int j) { return K_[tri(i, j)]; }
+    __device__ __forceinline__ void finishH()
+    {
+#pragma unroll
+        for (int e = 0; e < NT; ++e) Hs[e * kWave] = K_[e];
+    }
+    __device__ __forceinline__ double H(int i, int j) const { return Hs[tri(i, j) * kWave]; }
+    __device__ __forceinline__ double &K(int i, int j) { return K_[tri(i, j)]; }
+    __device__ __forceinline__ double &G(int r, int j) { return G_[r * N + j]; }
+    __device__ __forceinline__ double &g(int i) { return g_[i]; }
+    __device__ __forceinline__ double &w(int i) { return w_[i]; }
+    __device__ __forceinline__ double &lamU(int i) { return lamU_[i]; }
+    __device__ __forceinline__ double &lamL(int i) { return lamL_[i]; }
+    __device__ __forceinline__ double &nuU(int i) { return nuU_[i]; }
+    __device__ __forceinline__ double &nuL(int i) { return nuL_[i]; }
+    __device__ __forceinline__ double &hw(int i) { return hw_[i]; }
+    __device__ __forceinline__ double &dwa(int i) { return dwa_[i]; }
+    __device__ __forceinline__ double &dw(int i) { return dw_[i]; }
+    __device__ __forceinline__ double &rinv(int i) { return rinv_[i]; }
+    __device__ __forceinline__ double &isu(int i) { return isu_[i]; }
+    __device__ __forceinline__ double &isl(int i) { return isl_[i]; }
+    __device__ __forceinline__ double &iru(int i) { return iru_[i]; }
+    __device__ __forceinline__ double &irl(int i) { return irl_[i]; }
+    __device__ __forceinline__ double &sa02(int t) { return sa02_[t]; }
+    __device__ __forceinline__ double &sa12(int t) { return sa12_[t]; }
+    __device__ __forceinline__ double &sb(int t, int k) { return sb_[6 * t + k]; }
+    __device__ __forceinline__ double &sc(int t, int r) { return sc_[3 * t + r]; }
+    __device__ __forceinline__ double &theta(int t) { return theta_[t]; }
+    __device__ __forceinline__ double &uref(int r, int t) { return uref_[r * T + t]; }
+};
+
+struct MemStore {
+    static constexpr bool kStatic = false;
+    int T, N, NT;
+    double *base;    // workspace + instance index
+    int64_t stride;  // padded batch
+    int oH, oK, oG, og, ow, olU, olL, onU, onL, ohw, odwa, odw, orinv, oisu, oisl, oiru, oirl;
+    int osa02, osa12, osb, osc, oth, ouref, total;
+    __host__ __device__ void layout(int T_)
+    {
+        T = T_; N = 2 * T_; NT = N * (N + 1) / 2;
+        int o = 0;
+        oH = o; o += NT; oK = o; o += NT; oG = o; o += 3 * N;
+        og = o; o += N; ow = o; o += N; olU = o; o += N; olL = o; o += N; onU = o; o += N; onL = o; o += N;
+        ohw = o; o += N; odwa = o; o += N; odw = o; o += N; orinv = o; o += N;
+        oisu = o; o += N; oisl = o; o += N; oiru = o; o += N; oirl = o; o += N;
+        osa02 = o; o += T; osa12 = o; o += T; osb = o; o += 6 * T; osc = o; o += 3 * T;
+        oth = o; o += T; ouref = o; o += 4 * T;
+        total = o;
+    }
+    __device__ __forceinline__ int horizon() const { return T; }
+    __device__ __forceinline__ static int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+    __device__ __forceinline__ double &at(int o) { return base[(int64_t)o * stride]; }
+    __device__ __forceinline__ double &Hacc(int i, int j) { return at(oH + tri(i, j)); }
+    __device__ __forceinline__ void finishH() {}
+    __device__ __forceinline__ double H(int i, int j) { return at(oH + tri(i, j)); }
+    __device__ __forceinline__ double &K(int i, int j) { return at(oK + tri(i, j)); }
+    __device__ __forceinline__ double &G(int r, int j) { return at(oG + r * N + j); }
+    __device__ __forceinline__ double &g(int i) { return at(og + i); }
+    __device__ __forceinline__ double &w(int i) { return at(ow + i); }
+    __device__ __forceinline__ double &lamU(int i) { return at(olU + i); }
+    __device__ __forceinline__ double &lamL(int i) { return at(olL + i); }
+    __device__ __forceinline__ double &nuU(int i) { return at(onU + i); }
+    __device__ __forceinline__ double &nuL(int i) { return at(onL + i); }
+    __device__ __forceinline__ double &hw(int i) { return at(ohw + i); }
+    __device__ __forceinline__ double &dwa(int i) { return at(odwa + i); }
+    __device__ __forceinline__ double &dw(int i) { return at(odw + i); }
+    __device__ __forceinline__ double &rinv(int i) { return at(orinv + i); }
+    __device__ __forceinline__ double &isu(int i) { return at(oisu + i); }
+    __device__ __forceinline__ double &isl(int i) { return at(oisl + i); }
+    __device__ __forceinline__ double &iru(int i) { return at(oiru + i); }
+    __device__ __forceinline__ double &irl(int i) { return at(oirl + i); }
+    __device__ __forceinline__ double &sa02(int t) { return at(osa02 + t); }
+    __device__ __forceinline__ double &sa12(int t) { return at(osa12 + t); }
+    __device__ __forceinline__ double &sb(int t, int k) { return at(osb + 6 * t + k); }
+    __device__ __forceinline__ double &sc(int t, int r) { return at(osc + 3 * t + r); }
+    __device__ __forceinline__ double &theta(int t) { return at(oth + t); }
+    __device__ __forceinline__ double &uref(int r, int t) { return at(ouref + r * T + t); }
+};
+
+// ------------------------------------------------------------------------------------
+// condensed QP assembly
+//   x_t = p_t + G_t w,  p_{t+1} = A_t p_t + c_t,  G_{t+1} = A_t G_t with block t = B_t E
+//   H = 2 (Rw + D^T Rdw D + sum_t G_t^T Q_t G_t),  g = 2 sum_t G_t^T Q_t (p_t - xref_t)
+// Stage weights: none at t = 0 (`if t != 0`, mpc_diff_drive.py:181), Q * growth^t for
+// t = 1..T-1 (mpc_dsr.py:349), Qf at t = T.
+// ------------------------------------------------------------------------------------
+template <int MODEL, class S>
+__device__ __forceinline__ void assemble(S &s, const mpcx_variant &v, const double (&x0)[3],
+                                         const double *__restrict__ xref, bool roll_theta)
+{
+    const int T = s.horizon(), N = 2 * T, W = T + 1;
+    double rw[2], rdw[2];
+    if (v.eq_mode == MPCX_EQ_NONE) {
+        rw[0] = v.R[0]; rw[1] = v.R[1]; rdw[0] = v.Rd[0]; rdw[1] = v.Rd[1];
+    } else if (v.eq_mode == MPCX_EQ_FIXED_STEER) {
+        rw[0] = v.R[0]; rw[1] = v.R[2]; rdw[0] = v.Rd[0]; rdw[1] = v.Rd[2];
+    } else {
+        rw[0] = v.R[0] + v.R[2]; rw[1] = v.R[1] + v.R[3];
+        rdw[0] = v.Rd[0] + v.Rd[2]; rdw[1] = v.Rd[1] + v.Rd[3];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) s.Hacc(i, j) = 0.0;
+        s.g(i) = 0.0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) s.G(r, i) = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int c = i & 1, t = i >> 1;
+        double d = 2.0 * rw[c];
+        if (t > 0) d += 2.0 * rdw[c];
+        if (t + 1 < T) d += 2.0 * rdw[c];
+        s.Hacc(i, i) = d;
+        if (t > 0) s.Hacc(i, i - 2) = -2.0 * rdw[c];
+    }
+    double p[3] = {x0[0], x0[1], x0[2]};
+    double qg = 1.0;
+    double th = s.theta(0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        double u[4], Bm[3][4], C[3], a02, a12, omega;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = (MODEL == MPCX_MODEL_DIFF_DRIVE && r >= 2) ? 0.0 : s.uref(r, t);
+        if (!roll_theta) th = s.theta(t);
+        linearize<MODEL>(v, th, u, a02, a12, Bm, C, omega);
+        th = th + omega * v.dt;   // only used when roll_theta
+        double bt[3][2], ct[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (v.eq_mode == MPCX_EQ_NONE) {
+                bt[r][0] = Bm[r][0]; bt[r][1] = Bm[r][1]; ct[r] = C[r];
+            } else if (v.eq_mode == MPCX_EQ_ACKERMANN) {
+                bt[r][0] = Bm[r][0] + Bm[r][2]; bt[r][1] = Bm[r][1] - Bm[r][3]; ct[r] = C[r];
+            } else if (v.eq_mode == MPCX_EQ_CRAB) {
+                bt[r][0] = Bm[r][0] + Bm[r][2]; bt[r][1] = Bm[r][1] + Bm[r][3]; ct[r] = C[r];
+            } else {
+                bt[r][0] = Bm[r][0]; bt[r][1] = Bm[r][2];
+                ct[r] = C[r] + (Bm[r][1] + Bm[r][3]) * v.steer_fixed;
+            }
+        }
+        s.sa02(t) = a02; s.sa12(t) = a12;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { s.sb(t, 2 * r) = bt[r][0]; s.sb(t, 2 * r + 1) = bt[r][1]; s.sc(t, r) = ct[r]; }
+        const double pn0 = p[0] + a02 * p[2] + ct[0];
+        const double pn1 = p[1] + a12 * p[2] + ct[1];
+        const double pn2 = p[2] + ct[2];
+        p[0] = pn0; p[1] = pn1; p[2] = pn2;
+#pragma unroll
+        for (int j = 0; j < 2 * t; ++j) {
+            const double g2 = s.G(2, j);
+            s.G(0, j) += a02 * g2;
+            s.G(1, j) += a12 * g2;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { s.G(r, 2 * t) = bt[r][0]; s.G(r, 2 * t + 1) = bt[r][1]; }
+        const int ts = t + 1;
+        double Qs[3];
+        if (ts < T) {
+            qg *= v.q_growth;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Qs[r] = v.Q[r] * qg;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) Qs[r] = v.Qf[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double e = p[r] - xref[r * W + ts];
+            const double q2 = 2.0 * Qs[r];
+#pragma unroll
+            for (int i = 0; i < 2 * ts; ++i) {
+                const double gi = q2 * s.G(r, i);
+                s.g(i) += gi * e;
+#pragma unroll
+                for (int j = 0; j <= i; ++j) s.Hacc(i, j) += gi * s.G(r, j);
+            }
+        }
+    }
+    s.finishH();
+}
+
+// ------------------------------------------------------------------------------------
+// interior point solve of  min 1/2 w'Hw + g'w,  lo <= w <= hi,  |w[i+2]-w[i]| <= rr[i&1]
+// ------------------------------------------------------------------------------------
+template <bool ALL, class S>
+__device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_iter, bool skip,
+                                          int &status, int &iters)
+{
+    const int T = s.horizon(), N = 2 * T, NR = N - 2;
+    const bool bx[2] = {ALL || fb.box[0], ALL || fb.box[1]};
+    const bool bx0[2] = {ALL || fb.box0[0], ALL || fb.box0[1]};
+    const bool rt[2] = {ALL || fb.rate[0], ALL || fb.rate[1]};
+    auto hasbox = [&](int i) { return (i >> 1) == 0 ? bx0[i & 1] : bx[i & 1]; };
+    auto hi_of = [&](int i) { return (i >> 1) == 0 ? fb.hi0[i & 1] : fb.b[i & 1]; };
+    auto lo_of = [&](int i) { return (i >> 1) == 0 ? fb.lo0[i & 1] : -fb.b[i & 1]; };
+
+    // strictly feasible start: every stage at the middle of the first-stage window
+    double wc[2];
+    int m = 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        wc[c] = bx0[c] ? 0.5 * (fb.lo0[c] + fb.hi0[c]) : 0.0;
+        m += (bx0[c] ? 2 : 0) + (bx[c] ? 2 * (T - 1) : 0) + (rt[c] ? 2 * (T - 1) : 0);
+    }
+    const double inv_m = m > 0 ? 1.0 / (double)m : 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double wi = wc[i & 1];
+        s.w(i) = wi;
+        if (hasbox(i)) {
+            s.lamU(i) = kMu0 * rcp_nr(dmax(hi_of(i) - wi, kSlackMin));
+            s.lamL(i) = kMu0 * rcp_nr(dmax(wi - lo_of(i), kSlackMin));
+        } else {
+            s.lamU(i) = 0.0; s.lamL(i) = 0.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const double l0 = rt[i & 1] ? kMu0 * rcp_nr(fb.rr[i & 1]) : 0.0;
+        s.nuU(i) = l0; s.nuL(i) = l0;
+    }
+
+    bool done = skip;
+    int my_iters = 0;
+    status = MPCX_ST_FAILED;
+    for (int it = 0;; ++it) {
+        // K <- H and hw <- H w + g, one pass over the Hessian
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.hw(i) = s.g(i);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double wi = s.w(i);
+            double acc = s.hw(i);
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                const double h = s.H(i, j);
+                s.K(i, j) = h;
+                acc = fma(h, s.w(j), acc);
+                s.hw(j) = fma(h, wi, s.hw(j));
+            }
+            const double hd = s.H(i, i);
+            s.K(i, i) = hd;
+            s.hw(i) = fma(hd, wi, acc);
+        }
+        // slacks, barrier Hessian terms, C'lambda (kept in dw), complementarity
+        double musum = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.dw(i) = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (hasbox(i)) {
+                const double wi = s.w(i);
+                const double su = dmax(hi_of(i) - wi, kSlackMin), sl = dmax(wi - lo_of(i), kSlackMin);
+                const double iu = rcp_nr(su), il = rcp_nr(sl);
+                const double lu = s.lamU(i), ll = s.lamL(i);
+                s.isu(i) = iu; s.isl(i) = il;
+                s.K(i, i) += fma(lu, iu, ll * il);
+                s.dw(i) += lu - ll;
+                musum = fma(su, lu, fma(sl, ll, musum));
+            } else {
+                s.isu(i) = 0.0; s.isl(i) = 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (rt[i & 1]) {
+                const double rr = fb.rr[i & 1];
+                const double dv = s.w(i + 2) - s.w(i);
+                const double ru = dmax(rr - dv, kSlackMin), rl = dmax(rr + dv, kSlackMin);
+                const double iu = rcp_nr(ru), il = rcp_nr(rl);
+                const double nu = s.nuU(i), nl = s.nuL(i);
+                s.iru(i) = iu; s.irl(i) = il;
+                const double d = fma(nu, iu, nl * il);
+                s.K(i, i) += d;
+                s.K(i + 2, i + 2) += d;
+                s.K(i + 2, i) -= d;
+                const double dn = nu - nl;
+                s.dw(i + 2) += dn;
+                s.dw(i) -= dn;
+                musum = fma(ru, nu, fma(rl, nl, musum));
+            } else {
+                s.iru(i) = 0.0; s.irl(i) = 0.0;
+            }
+        }
+        const double mu = musum * inv_m;
+        double rdmax = 0.0, scale = 1.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double hwi = s.hw(i), gi = s.g(i), ci = s.dw(i);
+            rdmax = dmax(rdmax, fabs(hwi + ci));
+            scale = dmax(scale, dmax(fabs(hwi - gi), dmax(fabs(gi), fabs(ci))));
+        }
+        scale += 1.0;
+        const bool conv = rdmax <= kTolD * scale && mu <= kTolMu;
+        if (!done && conv) { done = true; status = MPCX_ST_OK; my_iters = it; }
+        if (__all(done) || it >= max_iter) {
+            if (!done) {
+                my_iters = it;
+                status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
+            }
+            break;
+        }
+
+        // Cholesky K = L L', right-looking, rinv = 1 / L_ii
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const double r = rsqrt_nr(s.K(j, j));
+            s.rinv(j) = r;
+#pragma unroll
+            for (int i = j + 1; i < N; ++i) s.K(i, j) *= r;
+#pragma unroll
+            for (int i = j + 1; i < N; ++i) {
+                const double lij = s.K(i, j);
+#pragma unroll
+                for (int k = j + 1; k <= i; ++k) s.K(i, k) = fma(-lij, s.K(k, j), s.K(i, k));
+            }
+        }
+        auto chol_solve = [&](auto &&vec) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double a = vec(i);
+#pragma unroll
+                for (int k = 0; k < i; ++k) a = fma(-s.K(i, k), vec(k), a);
+                vec(i) = a * s.rinv(i);
+            }
+#pragma unroll
+            for (int ii = 0; ii < N; ++ii) {
+                const int i = N - 1 - ii;
+                double a = vec(i);
+#pragma unroll
+                for (int k = i + 1; k < N; ++k) a = fma(-s.K(k, i), vec(k), a);
+                vec(i) = a * s.rinv(i);
+            }
+        };
+
+        // predictor: (H + C'DC) dwa = -(Hw + g)
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.dwa(i) = -s.hw(i);
+        chol_solve([&](int i) -> double & { return s.dwa(i); });
+
+        // x = (C dwa)_j / s_j ; primal ratio max x, dual ratio max (1 - x)
+        double rp = 0.0, rdm = 1.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (hasbox(i)) {
+                const double d = s.dwa(i);
+                const double xu = d * s.isu(i), xl = -d * s.isl(i);
+                rp = dmax(rp, dmax(xu, xl));
+                rdm = dmax(rdm, dmax(1.0 - xu, 1.0 - xl));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (rt[i & 1]) {
+                const double d = s.dwa(i + 2) - s.dwa(i);
+                const double yu = d * s.iru(i), yl = -d * s.irl(i);
+                rp = dmax(rp, dmax(yu, yl));
+                rdm = dmax(rdm, dmax(1.0 - yu, 1.0 - yl));
+            }
+        }
+        const double apa = rp > 1.0 ? rcp_nr(rp) : 1.0;
+        const double ada = rcp_nr(rdm);
+        double muaff = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (hasbox(i)) {
+                const double wi = s.w(i), d = s.dwa(i);
+                const double su = dmax(hi_of(i) - wi, kSlackMin), sl = dmax(wi - lo_of(i), kSlackMin);
+                const double xu = d * s.isu(i), xl = -d * s.isl(i);
+                muaff += (su * fma(-apa, xu, 1.0)) * (s.lamU(i) * fma(ada, xu - 1.0, 1.0));
+                muaff += (sl * fma(-apa, xl, 1.0)) * (s.lamL(i) * fma(ada, xl - 1.0, 1.0));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (rt[i & 1]) {
+                const double rr = fb.rr[i & 1];
+                const double dv = s.w(i + 2) - s.w(i), d = s.dwa(i + 2) - s.dwa(i);
+                const double ru = dmax(rr - dv, kSlackMin), rl = dmax(rr + dv, kSlackMin);
+                const double yu = d * s.iru(i), yl = -d * s.irl(i);
+                muaff += (ru * fma(-apa, yu, 1.0)) * (s.nuU(i) * fma(ada, yu - 1.0, 1.0));
+                muaff += (rl * fma(-apa, yl, 1.0)) * (s.nuL(i) * fma(ada, yl - 1.0, 1.0));
+            }
+        }
+        muaff *= inv_m;
+        const double ratio = muaff * rcp_nr(dmax(mu, 1e-300));
+        const double sm = ratio * ratio * ratio * mu;   // sigma * mu
+
+        // corrector: rhs = -(Hw+g) - C' q,  q_j = (sigma mu - ds_aff dl_aff)/s_j
+        //          = sigma mu / s_j + lambda_j x_j (x_j - 1)
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.dw(i) = -s.hw(i);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (hasbox(i)) {
+                const double d = s.dwa(i);
+                const double iu = s.isu(i), il = s.isl(i);
+                const double xu = d * iu, xl = -d * il;
+                const double qu = fma(sm, iu, s.lamU(i) * xu * (xu - 1.0));
+                const double ql = fma(sm, il, s.lamL(i) * xl * (xl - 1.0));
+                s.dw(i) -= qu - ql;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (rt[i & 1]) {
+                const double d = s.dwa(i + 2) - s.dwa(i);
+                const double iu = s.iru(i), il = s.irl(i);
+                const double yu = d * iu, yl = -d * il;
+                const double qu = fma(sm, iu, s.nuU(i) * yu * (yu - 1.0));
+                const double ql = fma(sm, il, s.nuL(i) * yl * (yl - 1.0));
+                const double q = qu - ql;
+                s.dw(i + 2) -= q;
+                s.dw(i) += q;
+            }
+        }
+        chol_solve([&](int i) -> double & { return s.dw(i); });
+
+        // dual steps (stored over the reciprocal slacks) and the two ratios
+        double rp2 = 0.0, rd2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (hasbox(i)) {
+                const double da = s.dwa(i), d = s.dw(i);
+                const double iu = s.isu(i), il = s.isl(i), lu = s.lamU(i), ll = s.lamL(i);
+                const double xu = da * iu, xl = -da * il;
+                const double qu = fma(sm, iu, lu * xu * (xu - 1.0));
+                const double ql = fma(sm, il, ll * xl * (xl - 1.0));
+                const double zu = d * iu, zl = -d * il;
+                const double dlu = fma(lu, zu, qu - lu), dll = fma(ll, zl, ql - ll);
+                rp2 = dmax(rp2, dmax(zu, zl));
+                rd2 = dmax(rd2, dmax(-dlu * rcp_raw(lu), -dll * rcp_raw(ll)));
+                s.isu(i) = dlu; s.isl(i) = dll;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (rt[i & 1]) {
+                const double da = s.dwa(i + 2) - s.dwa(i), d = s.dw(i + 2) - s.dw(i);
+                const double iu = s.iru(i), il = s.irl(i), nu = s.nuU(i), nl = s.nuL(i);
+                const double yu = da * iu, yl = -da * il;
+                const double qu = fma(sm, iu, nu * yu * (yu - 1.0));
+                const double ql = fma(sm, il, nl * yl * (yl - 1.0));
+                const double zu = d * iu, zl = -d * il;
+                const double dnu = fma(nu, zu, qu - nu), dnl = fma(nl, zl, ql - nl);
+                rp2 = dmax(rp2, dmax(zu, zl));
+                rd2 = dmax(rd2, dmax(-dnu * rcp_raw(nu), -dnl * rcp_raw(nl)));
+                s.iru(i) = dnu; s.irl(i) = dnl;
+            }
+        }
+        const double eta = dmin(kEtaCap, dmax(0.99, 1.0 - mu));
+        const double ap = rp2 > eta ? eta * rcp_nr(rp2) : 1.0;
+        const double ad = rd2 > eta ? eta * rcp_nr(rd2) : 1.0;
+        if (!done) {   // converged lanes keep their iterate while the rest of the wave finishes
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                s.w(i) = fma(ap, s.dw(i), s.w(i));
+                if (hasbox(i)) {
+                    s.lamU(i) = fma(ad, s.isu(i), s.lamU(i));
+                    s.lamL(i) = fma(ad, s.isl(i), s.lamL(i));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                if (rt[i & 1]) {
+                    s.nuU(i) = fma(ad, s.iru(i), s.nuU(i));
+                    s.nuL(i) = fma(ad, s.irl(i), s.nuL(i));
+                }
+            }
+        }
+    }
+    iters = my_iters;
+}
+
+}  // namespace mpcx

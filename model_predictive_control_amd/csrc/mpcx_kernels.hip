@@ -1,0 +1,631 @@
+// Kernels and C ABI of libmpcx.so (gfx950 only).  See include/mpcx.h for the contract.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "mpcx.h"
+#include "mpcx_device.h"
+
+namespace mpcx {
+
+// ------------------------------------------------------------------------------------
+// solve: one instance per lane
+// ------------------------------------------------------------------------------------
+struct SolveArgs {
+    mpcx_variant v;
+    int64_t B;
+    const double *x0, *xref, *xbar, *uin;
+    const uint8_t *has_prev;
+    double *u_out, *x_out, *obj_out;
+    int32_t *status_out, *iters_out;
+    int32_t linear_mode;   // 1: (xbar, uref) given -> one QP;  0: cold start + rollout (+ chain)
+    int32_t max_iter;
+};
+
+template <int MODEL, bool ALL, class S>
+__device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b, bool live)
+{
+    const mpcx_variant &v = a.v;
+    constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
+    const int T = s.horizon(), W = T + 1;
+    const double *__restrict__ xr = a.xref + b * 3 * W;
+    double x0[3] = {a.x0[b * 3], a.x0[b * 3 + 1], a.x0[b * 3 + 2]};
+    bool finite = finite_d(x0[0]) && finite_d(x0[1]) && finite_d(x0[2]);
+#pragma unroll
+    for (int i = 0; i < 3 * W; ++i) finite = finite && finite_d(xr[i]);
+
+    const double *uin = a.uin ? a.uin + b * NU * T : nullptr;
+    const bool warm = a.linear_mode || (uin && (!a.has_prev || a.has_prev[b]));
+    const int chain = a.linear_mode ? 1 : (v.chain > 1 ? (v.chain < T ? v.chain : T) : 1);
+    bool roll_theta = false;
+
+    if (a.linear_mode) {
+        const double *xb = a.xbar + b * 3 * W;
+#pragma unroll
+        for (int i = 0; i < 3 * W; ++i) finite = finite && finite_d(xb[i]);
+#pragma unroll
+        for (int t = 0; t < T; ++t) s.theta(t) = xb[2 * W + t];
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double val = 0.0;
+            if (r < NU) val = warm ? uin[r * T + t] : v.cold_start[r];
+            finite = finite && finite_d(val);
+            s.uref(r, t) = val;
+        }
+    if (!a.linear_mode) {
+        if (chain <= 1) {
+            s.theta(0) = x0[2];
+            roll_theta = true;   // yaw of predict_motion is produced while linearising
+        } else {
+            // mpc_sim.py:294: xbar comes from the incoming controls and stays fixed while the
+            // chained solves refill uref column by column (:295-308)
+            double th = x0[2];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                s.theta(t) = th;
+                double u[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[r] = s.uref(r, t);
+                th = th + yaw_rate<MODEL>(v, u) * v.dt;
+            }
+#pragma unroll
+            for (int t = 1; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s.uref(r, t) = 0.0;
+        }
+    }
+
+    int status = MPCX_ST_OK, iters = 0;
+    bool skip = !finite;
+    if (!finite) {
+        status = MPCX_ST_NONFINITE;
+        x0[0] = x0[1] = x0[2] = 0.0;
+    }
+    const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
+    auto controls = [&](int t, double (&u)[4]) {
+        const double w0 = s.w(2 * t), w1 = s.w(2 * t + 1);
+        if (v.eq_mode == MPCX_EQ_NONE) { u[0] = w0; u[1] = w1; u[2] = 0.0; u[3] = 0.0; }
+        else if (v.eq_mode == MPCX_EQ_FIXED_STEER) { u[0] = w0; u[1] = v.steer_fixed; u[2] = w1; u[3] = v.steer_fixed; }
+        else { u[0] = w0; u[1] = w1; u[2] = w0; u[3] = sg * w1; }
+    };
+
+    for (int pass = 0; pass < chain; ++pass) {
+        if (pass > 0) {   // column `pass` of uref <- previous solution (mpc_sim.py:296-299 after :302)
+#pragma unroll
+            for (int t = 1; t < T; ++t) {   // static indices, runtime predicate: keeps the arrays in registers
+                if (t == pass) {
+                    double u[4];
+                    controls(t, u);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s.uref(r, t) = u[r];
+                }
+            }
+        }
+        assemble<MODEL>(s, v, x0, xr, roll_theta);
+        double u0[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u0[r] = s.uref(r, 0);
+        FreeBounds fb;
+        free_bounds(v, u0, fb);
+        if (!fb.feasible && !skip) { skip = true; status = MPCX_ST_INFEASIBLE; }
+        int st = MPCX_ST_OK, it = 0;
+        ipm_solve<ALL>(s, fb, a.max_iter, skip, st, it);
+        if (!skip) {
+            iters += it;
+            status = st;
+            if (st == MPCX_ST_FAILED) skip = true;
+        }
+    }
+
+    // controls, predicted states, objective (cost expression of mpc_diff_drive.py:178-193
+    // plus the difference term of mpc.py:152-153, evaluated at the returned point)
+    const bool bad = status == MPCX_ST_NONFINITE || status == MPCX_ST_INFEASIBLE;
+    const double nan = __builtin_nan("");
+    double J = 0.0, qg = 1.0;
+    double x[3] = {x0[0], x0[1], x0[2]};
+    double up[4] = {0, 0, 0, 0};
+    double *uo = a.u_out + b * NU * T, *xo = a.x_out + b * 3 * W;
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xo[r * W] = bad ? nan : x[r];
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        double u[4];
+        controls(t, u);
+        const double w0 = s.w(2 * t), w1 = s.w(2 * t + 1);
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+            J = fma(v.R[r] * u[r], u[r], J);
+            if (t > 0) { const double d = u[r] - up[r]; J = fma(v.Rd[r] * d, d, J); }
+            up[r] = u[r];
+            if (live) uo[r * T + t] = bad ? nan : u[r];
+        }
+        const double n0 = x[0] + s.sa02(t) * x[2] + s.sb(t, 0) * w0 + s.sb(t, 1) * w1 + s.sc(t, 0);
+        const double n1 = x[1] + s.sa12(t) * x[2] + s.sb(t, 2) * w0 + s.sb(t, 3) * w1 + s.sc(t, 1);
+        const double n2 = x[2] + s.sb(t, 4) * w0 + s.sb(t, 5) * w1 + s.sc(t, 2);
+        x[0] = n0; x[1] = n1; x[2] = n2;
+        const int ts = t + 1;
+        if (ts < T) qg *= v.q_growth;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double e = xr[r * W + ts] - x[r];
+            const double q = ts < T ? v.Q[r] * qg : v.Qf[r];
+            J = fma(q * e, e, J);
+            if (live) xo[r * W + ts] = bad ? nan : x[r];
+        }
+    }
+    if (live) {
+        a.obj_out[b] = bad ? nan : J;
+        a.status_out[b] = status;
+        if (a.iters_out) a.iters_out[b] = iters;
+    }
+}
+
+template <int MODEL, int T, bool ALL>
+__global__ __launch_bounds__(kWave) void k_solve_reg(SolveArgs a)
+{
+    __shared__ double Hs[RegStore<T>::NT * kWave];
+    RegStore<T> s;
+    s.Hs = Hs + threadIdx.x;
+    int64_t b = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    const bool live = b < a.B;
+    if (!live) b = a.B - 1;   // idle lanes redo the last instance so wave votes stay uniform
+    run_instance<MODEL, ALL>(s, a, b, live);
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kWave) void k_solve_mem(SolveArgs a, double *ws, int64_t stride)
+{
+    MemStore s;
+    s.layout(a.v.T);
+    const int64_t slot = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    s.base = ws + slot;
+    s.stride = stride;
+    int64_t b = slot;
+    const bool live = b < a.B;
+    if (!live) b = a.B - 1;
+    run_instance<MODEL, false>(s, a, b, live);
+}
+
+// ------------------------------------------------------------------------------------
+// predict_motion / get_linear_model_matrix as stand-alone batched operators
+// ------------------------------------------------------------------------------------
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_rollout(mpcx_variant v, int64_t B, const double *__restrict__ x0,
+                                                 const double *__restrict__ u, double *__restrict__ xbar)
+{
+    constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int T = v.T, W = T + 1;
+    double x = x0[b * 3], y = x0[b * 3 + 1], yaw = x0[b * 3 + 2];
+    double *xb = xbar + b * 3 * W;
+    const double *ub = u + b * NU * T;
+    xb[0] = x; xb[W] = y; xb[2 * W] = yaw;
+    for (int t = 0; t < T; ++t) {
+        double uu[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < NU; ++r) uu[r] = ub[r * T + t];
+        plant_step<MODEL>(v, x, y, yaw, uu);
+        xb[t + 1] = x; xb[W + t + 1] = y; xb[2 * W + t + 1] = yaw;
+    }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_linearize(mpcx_variant v, int64_t B, const double *__restrict__ theta,
+                                                   const double *__restrict__ u, double *__restrict__ A,
+                                                   double *__restrict__ Bo, double *__restrict__ C)
+{
+    constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double uu[4] = {0, 0, 0, 0}, Bm[3][4], Cc[3], a02, a12, om;
+#pragma unroll
+    for (int r = 0; r < NU; ++r) uu[r] = u[b * NU + r];
+    linearize<MODEL>(v, theta[b], uu, a02, a12, Bm, Cc, om);
+    double *Ab = A + b * 9;
+    Ab[0] = 1; Ab[1] = 0; Ab[2] = a02; Ab[3] = 0; Ab[4] = 1; Ab[5] = a12; Ab[6] = 0; Ab[7] = 0; Ab[8] = 1;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) Bo[(b * 3 + r) * NU + k] = Bm[r][k];
+        C[b * 3 + r] = Cc[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// nearest course point + reference window: 16 lanes per instance.
+// Lane k of a group looks at course point pind + k (+16 per extra sweep), the group
+// reduces (distance, index) with lexicographic min so ties go to the lowest index like
+// list.index(min(d)) does (mpc_diff_drive.py:110-112), and lanes 0..T write the columns.
+// Distances are dx*dx + dy*dy in float64 with no fused multiply-add: the index has to be
+// bit-exact.
+// ------------------------------------------------------------------------------------
+constexpr int kGroup = 16;
+
+__global__ __launch_bounds__(256) void k_nearest_ref(int mode, int T, double dt, double param, int n_search,
+                                                     int sign, int64_t B, const double *__restrict__ state,
+                                                     const int32_t *__restrict__ course_id,
+                                                     const int32_t *__restrict__ pind_in,
+                                                     const double *__restrict__ cx, const double *__restrict__ cy,
+                                                     const double *__restrict__ cyaw,
+                                                     const int32_t *__restrict__ clen, int64_t Lmax,
+                                                     int32_t *__restrict__ ind_out, double *__restrict__ mind_out,
+                                                     double *__restrict__ xref_out)
+{
+    const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+    const int k = threadIdx.x % kGroup;
+    const bool live = gid < B;
+    const int64_t b = live ? gid : B - 1;
+    const int64_t course = course_id ? course_id[b] : 0;
+    const double *tx = cx + course * Lmax, *ty = cy + course * Lmax, *tw = cyaw + course * Lmax;
+    const int len = clen[course];
+    const int pind = pind_in[b];
+    const double x = state[4 * b], y = state[4 * b + 1];
+    const int lo = pind < len ? pind : len;
+    const int hi = pind + n_search < len ? pind + n_search : len;
+    double best = kBig;
+    int bi = 0x7fffffff;
+    for (int j = lo + k; j < hi; j += kGroup) {
+        const double dx = x - tx[j], dy = y - ty[j];
+        const double d = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+        if (d < best) { best = d; bi = j; }   // increasing j per lane: strict < keeps the first
+    }
+#pragma unroll
+    for (int off = kGroup / 2; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, kGroup);
+        const int oi = __shfl_xor(bi, off, kGroup);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    const bool empty = pind < 0 || hi <= lo;
+    const int W = T + 1;
+    if (empty) {
+        if (live && k == 0) {
+            ind_out[b] = -1;
+            if (mind_out) mind_out[b] = __builtin_nan("");
+        }
+        if (live && xref_out)
+            for (int i = k; i < 3 * W; i += kGroup) xref_out[b * 3 * W + i] = __builtin_nan("");
+        return;
+    }
+    if (live && k == 0 && mind_out) {
+        double m = sqrt(best);
+        if (sign) {
+            double ang = tw[bi] - atan2(ty[bi] - y, tx[bi] - x);
+            while (ang > M_PI) ang -= 2.0 * M_PI;     // pi_2_pi, mpc_diff_drive.py:66-73
+            while (ang < -M_PI) ang += 2.0 * M_PI;
+            if (ang < 0) m = -m;
+        }
+        mind_out[b] = m;
+    }
+    int ind = bi;
+    if (pind >= ind) ind = pind;   // mpc_diff_drive.py:247-248
+    if (live && k == 0) ind_out[b] = ind;
+    if (!live || !xref_out) return;
+    double *xr = xref_out + b * 3 * W;
+    if (mode == 0) {
+        // calc_ref_trajectory: travel accumulates sequentially, int(round()) is half-to-even
+        const double step = fabs(state[4 * b + 3]) * dt;
+        double travel = 0.0;
+        for (int i = 0; i < W; ++i) {
+            travel += step;
+            if (i % kGroup != k) continue;
+            const long dind = (long)rint(travel / param);
+            const long kk = ind + dind < len ? ind + dind : len - 1;
+            xr[i] = tx[kk]; xr[W + i] = ty[kk]; xr[2 * W + i] = tw[kk];
+        }
+    } else {
+        int cnt = (int)param;
+        if (ind + cnt > len) cnt = len - ind;
+        for (int i = k; i < W; i += kGroup) {
+            const int kk = ind + (i < cnt ? i : cnt - 1);
+            xr[i] = tx[kk]; xr[W + i] = ty[kk]; xr[2 * W + i] = tw[kk];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char *what)
+{
+    return fail(MPCX_E_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+static int check_variant(const mpcx_variant *v)
+{
+    if (!v) return fail(MPCX_E_ARG, "variant is NULL");
+    if (v->T < 1 || v->T > MPCX_MAX_T) return fail(MPCX_E_ARG, "horizon T=%d outside 1..%d", v->T, MPCX_MAX_T);
+    if (v->model == MPCX_MODEL_DIFF_DRIVE) {
+        if (v->nu != 2 || v->eq_mode != MPCX_EQ_NONE)
+            return fail(MPCX_E_ARG, "diff-drive needs nu=2 and eq_mode NONE");
+    } else if (v->model == MPCX_MODEL_DSR) {
+        if (v->nu != 4 || v->eq_mode < MPCX_EQ_ACKERMANN || v->eq_mode > MPCX_EQ_FIXED_STEER)
+            return fail(MPCX_E_ARG, "dual-steer needs nu=4 and an ackermann/crab/fixed-steer equality map");
+    } else {
+        return fail(MPCX_E_ARG, "unknown model %d", v->model);
+    }
+    if (!(v->dt > 0.0) || !(v->wb > 0.0)) return fail(MPCX_E_ARG, "dt and wb must be positive");
+    return 0;
+}
+
+// every free channel has a finite box and a finite rate bound -> branch-free solver
+static bool all_present(const mpcx_variant *v)
+{
+    auto fin = [](double x) { return std::isfinite(x); };
+    if (v->eq_mode == MPCX_EQ_NONE) return fin(v->umax[0]) && fin(v->umax[1]) && fin(v->dumax[0]) && fin(v->dumax[1]);
+    if (v->eq_mode == MPCX_EQ_FIXED_STEER)
+        return fin(v->umax[0]) && fin(v->umax[2]) && fin(v->dumax[0]) && fin(v->dumax[2]);
+    return (fin(v->umax[0]) || fin(v->umax[2])) && (fin(v->umax[1]) || fin(v->umax[3])) &&
+           (fin(v->dumax[0]) || fin(v->dumax[2])) && (fin(v->dumax[1]) || fin(v->dumax[3]));
+}
+
+static bool uses_registers(const mpcx_variant *v) { return v->T == 5; }
+
+// grow-only per-device workspace for the memory-resident path
+static std::mutex g_ws_mutex;
+static double *g_ws[64] = {nullptr};
+static size_t g_ws_bytes[64] = {0};
+constexpr int64_t kChunk = 32768;   // instances per launch on the memory-resident path
+
+static int64_t ws_doubles_per_instance(int T)
+{
+    MemStore s;
+    s.layout(T);
+    return s.total;
+}
+
+static int launch_solve(const SolveArgs &a, hipStream_t st)
+{
+    const mpcx_variant *v = &a.v;
+    if (a.B == 0) return 0;
+    if (uses_registers(v)) {
+        const dim3 grid((unsigned)((a.B + kWave - 1) / kWave)), block(kWave);
+        const bool all = all_present(v);
+        if (v->model == MPCX_MODEL_DIFF_DRIVE) {
+            if (all) hipLaunchKernelGGL((k_solve_reg<0, 5, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_solve_reg<0, 5, false>), grid, block, 0, st, a);
+        } else {
+            if (all) hipLaunchKernelGGL((k_solve_reg<1, 5, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_solve_reg<1, 5, false>), grid, block, 0, st, a);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "k_solve_reg launch");
+        return 0;
+    }
+    // memory-resident path, chunked so the workspace stays bounded
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+    if (dev < 0 || dev >= 64) return fail(MPCX_E_UNSUPPORTED, "device index %d", dev);
+    constexpr int NUmax = 4;
+    (void)NUmax;
+    const int NU = v->nu, T = v->T, W = T + 1;
+    const int64_t chunk = a.B < kChunk ? ((a.B + kWave - 1) / kWave) * kWave : kChunk;
+    const size_t need = (size_t)ws_doubles_per_instance(T) * (size_t)chunk * sizeof(double);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    if (g_ws_bytes[dev] < need) {
+        if (g_ws[dev]) {
+            e = hipDeviceSynchronize();   // earlier launches may still use the old buffer
+            if (e != hipSuccess) return hip_fail(e, "hipDeviceSynchronize");
+            (void)hipFree(g_ws[dev]);
+            g_ws[dev] = nullptr;
+            g_ws_bytes[dev] = 0;
+        }
+        e = hipMalloc((void **)&g_ws[dev], need);
+        if (e != hipSuccess) return fail(MPCX_E_NOMEM, "workspace of %zu bytes: %s", need, hipGetErrorString(e));
+        g_ws_bytes[dev] = need;
+    }
+    for (int64_t off = 0; off < a.B; off += chunk) {
+        SolveArgs c = a;
+        c.B = a.B - off < chunk ? a.B - off : chunk;
+        c.x0 = a.x0 + off * 3;
+        c.xref = a.xref + off * 3 * W;
+        if (a.xbar) c.xbar = a.xbar + off * 3 * W;
+        if (a.uin) c.uin = a.uin + off * NU * T;
+        if (a.has_prev) c.has_prev = a.has_prev + off;
+        c.u_out = a.u_out + off * NU * T;
+        c.x_out = a.x_out + off * 3 * W;
+        c.obj_out = a.obj_out + off;
+        c.status_out = a.status_out + off;
+        if (a.iters_out) c.iters_out = a.iters_out + off;
+        const dim3 grid((unsigned)((c.B + kWave - 1) / kWave)), block(kWave);
+        if (v->model == MPCX_MODEL_DIFF_DRIVE)
+            hipLaunchKernelGGL((k_solve_mem<0>), grid, block, 0, st, c, g_ws[dev], chunk);
+        else
+            hipLaunchKernelGGL((k_solve_mem<1>), grid, block, 0, st, c, g_ws[dev], chunk);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "k_solve_mem launch");
+    }
+    return 0;
+}
+
+}  // namespace mpcx
+
+using namespace mpcx;
+
+extern "C" {
+
+int mpcx_abi_version(void) { return MPCX_ABI_VERSION; }
+
+const char *mpcx_last_error(void) { return g_err; }
+
+int mpcx_variant_by_name(const char *name, mpcx_variant *out)
+{
+    if (!name || !out) return fail(MPCX_E_ARG, "NULL argument");
+    const double inf = INFINITY, d45 = M_PI / 4.0, d90 = M_PI / 2.0;
+    mpcx_variant v;
+    memset(&v, 0, sizeof(v));
+    // shared dual-steer defaults (mpc_dsr.py:20-48, mpc_sim.py:167-195)
+    v.model = MPCX_MODEL_DSR; v.nu = 4; v.T = 5; v.chain = 1; v.dt = 0.2; v.wb = 1.0;
+    for (int i = 0; i < 4; ++i) { v.R[i] = 0.01; v.Rd[i] = 0.0; v.umax[i] = inf; v.dumax[i] = inf; v.first_step[i] = inf; }
+    v.Q[0] = 1.0; v.Q[1] = 1.0; v.Q[2] = 0.5; v.q_growth = 1.0;
+    v.Qf[0] = 1.0; v.Qf[1] = 1.0; v.Qf[2] = 0.5;
+    auto steer_mode = [&](int eq, double vmax, double smax, double dv, double dsteer) {
+        v.eq_mode = eq;
+        v.umax[0] = v.umax[2] = vmax; v.umax[1] = v.umax[3] = smax;
+        v.dumax[0] = v.dumax[2] = dv; v.dumax[1] = v.dumax[3] = dsteer;
+        v.first_step[1] = v.first_step[3] = dsteer;
+    };
+    auto fixed_mode = [&](double vmax, double dv) {
+        v.eq_mode = MPCX_EQ_FIXED_STEER;
+        v.steer_fixed = d90;
+        v.umax[0] = v.umax[2] = vmax;
+        v.dumax[0] = v.dumax[2] = dv;
+    };
+    if (!strcmp(name, "diff_drive")) {            // mpc_diff_drive.py:19-48,170-217
+        v.model = MPCX_MODEL_DIFF_DRIVE; v.nu = 2; v.eq_mode = MPCX_EQ_NONE;
+        v.umax[0] = 0.47; v.umax[1] = 3.77; v.dumax[0] = 0.2; v.dumax[1] = 1.0;
+        v.cold_start[0] = 0.3;
+        v.R[2] = v.R[3] = 0.0;
+    } else if (!strcmp(name, "dsr_ackermann")) {  // mpc_dsr.py:201-267
+        steer_mode(MPCX_EQ_ACKERMANN, 0.47, d90, 0.5 * 0.2, d45 * 0.2);
+    } else if (!strcmp(name, "dsr_crab")) {       // mpc_dsr.py:269-335
+        steer_mode(MPCX_EQ_CRAB, 0.47, d90, 0.5 * 0.2, d45 * 0.2);
+    } else if (!strcmp(name, "dsr_diff")) {       // mpc_dsr.py:337-395
+        fixed_mode(0.47, 0.5 * 0.2);
+        v.q_growth = 2.0;
+    } else if (!strcmp(name, "sim_ackermann")) {  // mpc_sim.py:312-380
+        steer_mode(MPCX_EQ_ACKERMANN, 0.47, d45, 0.2 * 0.2, d45 * 0.2);
+        v.chain = 5;
+    } else if (!strcmp(name, "sim_diff")) {       // mpc_sim.py:382-440
+        fixed_mode(0.47, 0.2 * 0.2);
+        v.chain = 5;
+    } else if (!strcmp(name, "sim_crab")) {       // mpc_sim.py:442-508
+        steer_mode(MPCX_EQ_CRAB, 0.5, d45, 0.2 * 0.2, d45 * 0.2);
+        v.chain = 5;
+    } else if (!strcmp(name, "mpc_py")) {         // mpc.py:33-47,117-187
+        v.T = 10; v.dt = 0.1; v.eq_mode = MPCX_EQ_ACKERMANN;
+        for (int i = 0; i < 4; ++i) { v.R[i] = 0.001; v.Rd[i] = 0.001; }
+        v.Q[0] = v.Q[1] = v.Q[2] = 0.1;
+        v.Qf[0] = v.Qf[1] = 0.1; v.Qf[2] = 0.0;
+        v.umax[0] = v.umax[2] = 0.5; v.umax[1] = v.umax[3] = 3.14;
+        v.dumax[1] = v.dumax[3] = 3 * 0.1;
+        v.first_step[1] = v.first_step[3] = 3 * 0.1;
+    } else {
+        return fail(MPCX_E_ARG, "unknown variant '%s'", name);
+    }
+    *out = v;
+    return 0;
+}
+
+int64_t mpcx_workspace_bytes(const mpcx_variant *v, int64_t B)
+{
+    if (check_variant(v) != 0 || B < 0) return MPCX_E_ARG;
+    if (uses_registers(v)) return 0;
+    const int64_t chunk = B < kChunk ? ((B + kWave - 1) / kWave) * kWave : kChunk;
+    return ws_doubles_per_instance(v->T) * chunk * (int64_t)sizeof(double);
+}
+
+int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const double *xref,
+                     const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,
+                     double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream)
+{
+    int rc = check_variant(v);
+    if (rc) return rc;
+    if (B < 0) return fail(MPCX_E_ARG, "negative batch");
+    if (B > 0 && (!x0 || !xref || !u_out || !x_out || !obj_out || !status_out))
+        return fail(MPCX_E_ARG, "NULL buffer");
+    SolveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.v = *v; a.B = B; a.x0 = x0; a.xref = xref; a.xbar = nullptr; a.uin = uprev; a.has_prev = has_prev;
+    a.u_out = u_out; a.x_out = x_out; a.obj_out = obj_out; a.status_out = status_out; a.iters_out = iters_out;
+    a.linear_mode = 0;
+    a.max_iter = 60;
+    return launch_solve(a, (hipStream_t)stream);
+}
+
+int mpcx_linear_mpc_batch(const mpcx_variant *v, int64_t B, const double *xref, const double *xbar,
+                          const double *x0, const double *uref, double *u_out, double *x_out,
+                          double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream)
+{
+    int rc = check_variant(v);
+    if (rc) return rc;
+    if (B < 0) return fail(MPCX_E_ARG, "negative batch");
+    if (B > 0 && (!x0 || !xref || !xbar || !uref || !u_out || !x_out || !obj_out || !status_out))
+        return fail(MPCX_E_ARG, "NULL buffer");
+    SolveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.v = *v; a.B = B; a.x0 = x0; a.xref = xref; a.xbar = xbar; a.uin = uref; a.has_prev = nullptr;
+    a.u_out = u_out; a.x_out = x_out; a.obj_out = obj_out; a.status_out = status_out; a.iters_out = iters_out;
+    a.linear_mode = 1;
+    a.max_iter = 60;
+    return launch_solve(a, (hipStream_t)stream);
+}
+
+int mpcx_rollout_batch(const mpcx_variant *v, int64_t B, const double *x0, const double *u, double *xbar,
+                       void *stream)
+{
+    int rc = check_variant(v);
+    if (rc) return rc;
+    if (B < 0) return fail(MPCX_E_ARG, "negative batch");
+    if (B == 0) return 0;
+    if (!x0 || !u || !xbar) return fail(MPCX_E_ARG, "NULL buffer");
+    const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    if (v->model == MPCX_MODEL_DIFF_DRIVE)
+        hipLaunchKernelGGL((k_rollout<0>), grid, block, 0, (hipStream_t)stream, *v, B, x0, u, xbar);
+    else
+        hipLaunchKernelGGL((k_rollout<1>), grid, block, 0, (hipStream_t)stream, *v, B, x0, u, xbar);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "k_rollout launch");
+}
+
+int mpcx_linearize_batch(const mpcx_variant *v, int64_t B, const double *theta, const double *u, double *A,
+                         double *Bm, double *C, void *stream)
+{
+    int rc = check_variant(v);
+    if (rc) return rc;
+    if (B < 0) return fail(MPCX_E_ARG, "negative batch");
+    if (B == 0) return 0;
+    if (!theta || !u || !A || !Bm || !C) return fail(MPCX_E_ARG, "NULL buffer");
+    const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    if (v->model == MPCX_MODEL_DIFF_DRIVE)
+        hipLaunchKernelGGL((k_linearize<0>), grid, block, 0, (hipStream_t)stream, *v, B, theta, u, A, Bm, C);
+    else
+        hipLaunchKernelGGL((k_linearize<1>), grid, block, 0, (hipStream_t)stream, *v, B, theta, u, A, Bm, C);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "k_linearize launch");
+}
+
+int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int32_t n_search, int32_t sign,
+                           int64_t B, const double *state, const int32_t *course_id, const int32_t *pind,
+                           const double *cx, const double *cy, const double *cyaw, const int32_t *clen,
+                           int64_t n_courses, int64_t Lmax, int32_t *ind_out, double *mind_out,
+                           double *xref_out, void *stream)
+{
+    if (mode != 0 && mode != 1) return fail(MPCX_E_ARG, "mode must be 0 or 1");
+    if (T < 1 || T > MPCX_MAX_T) return fail(MPCX_E_ARG, "horizon T=%d outside 1..%d", T, MPCX_MAX_T);
+    if (n_search < 1) return fail(MPCX_E_ARG, "n_search must be >= 1");
+    if (mode == 0 && !(param > 0.0)) return fail(MPCX_E_ARG, "dl must be positive");
+    if (mode == 1 && !(param >= 1.0)) return fail(MPCX_E_ARG, "n_search_ind must be >= 1");
+    if (B < 0 || n_courses < 1 || Lmax < 1) return fail(MPCX_E_ARG, "bad sizes");
+    if (B == 0) return 0;
+    if (!state || !pind || !cx || !cy || !cyaw || !clen || !ind_out) return fail(MPCX_E_ARG, "NULL buffer");
+    const int64_t threads = B * kGroup;
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_nearest_ref, grid, block, 0, (hipStream_t)stream, mode, T, dt, param, n_search, sign, B,
+                       state, course_id, pind, cx, cy, cyaw, clen, Lmax, ind_out, mind_out, xref_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "k_nearest_ref launch");
+}
+
+}  // extern "C"

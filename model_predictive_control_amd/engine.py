@@ -1,0 +1,156 @@
+"""Batched operators on device tensors.  torch is only used for device memory and the
+current HIP stream; every computation happens in libmpcx.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import CVariant
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise _lib.MpcxError("no GPU visible: the mpcx engine runs on MI355X only (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _dev(a, dtype=torch.float64) -> torch.Tensor:
+    """numpy / list / tensor -> contiguous device tensor of `dtype`."""
+    if isinstance(a, torch.Tensor):
+        t = a
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(device=_device(), dtype=dtype, non_blocking=False).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _outputs(B: int, NU: int, T: int, dev) -> Dict[str, torch.Tensor]:
+    return dict(u=torch.empty((B, NU, T), dtype=torch.float64, device=dev),
+                x=torch.empty((B, 3, T + 1), dtype=torch.float64, device=dev),
+                obj=torch.empty((B,), dtype=torch.float64, device=dev),
+                status=torch.empty((B,), dtype=torch.int32, device=dev),
+                iters=torch.empty((B,), dtype=torch.int32, device=dev))
+
+
+def solve_batch(v: CVariant, x0, xref, uprev=None, has_prev=None, out=None) -> Dict[str, torch.Tensor]:
+    """iterative_linear_mpc_control for B instances: x0 [B,3], xref [B,3,T+1],
+    uprev [B,NU,T] or None (cold start), has_prev [B] uint8 or None."""
+    lib = _lib.load()
+    x0 = _dev(x0)
+    xref = _dev(xref)
+    B, T, NU = x0.shape[0], v.T, v.nu
+    if tuple(x0.shape) != (B, 3) or tuple(xref.shape) != (B, 3, T + 1):
+        raise ValueError(f"x0 must be [B,3] and xref [B,3,{T + 1}]")
+    if uprev is not None:
+        uprev = _dev(uprev)
+        if tuple(uprev.shape) != (B, NU, T):
+            raise ValueError(f"uprev must be [B,{NU},{T}]")
+    if has_prev is not None:
+        has_prev = _dev(has_prev, torch.uint8)
+        if tuple(has_prev.shape) != (B,):
+            raise ValueError("has_prev must be [B]")
+    if out is None:
+        out = _outputs(B, NU, T, x0.device)
+    _lib.check(lib.mpcx_solve_batch(C.byref(v), B, _ptr(x0), _ptr(xref), _ptr(uprev), _ptr(has_prev),
+                                    _ptr(out["u"]), _ptr(out["x"]), _ptr(out["obj"]), _ptr(out["status"]),
+                                    _ptr(out["iters"]), _stream()))
+    return out
+
+
+def linear_mpc_batch(v: CVariant, xref, xbar, x0, uref, out=None) -> Dict[str, torch.Tensor]:
+    """linear_mpc_control* for B instances at the linearisation point (xbar, uref)."""
+    lib = _lib.load()
+    x0 = _dev(x0)
+    xref = _dev(xref)
+    xbar = _dev(xbar)
+    uref = _dev(uref)
+    B, T, NU = x0.shape[0], v.T, v.nu
+    if tuple(x0.shape) != (B, 3) or tuple(xref.shape) != (B, 3, T + 1) or tuple(xbar.shape) != (B, 3, T + 1) \
+            or tuple(uref.shape) != (B, NU, T):
+        raise ValueError("shape mismatch")
+    if out is None:
+        out = _outputs(B, NU, T, x0.device)
+    _lib.check(lib.mpcx_linear_mpc_batch(C.byref(v), B, _ptr(xref), _ptr(xbar), _ptr(x0), _ptr(uref),
+                                         _ptr(out["u"]), _ptr(out["x"]), _ptr(out["obj"]), _ptr(out["status"]),
+                                         _ptr(out["iters"]), _stream()))
+    return out
+
+
+def rollout_batch(v: CVariant, x0, u) -> torch.Tensor:
+    """predict_motion for B instances: xbar [B,3,T+1]."""
+    lib = _lib.load()
+    x0 = _dev(x0)
+    u = _dev(u)
+    B = x0.shape[0]
+    if tuple(u.shape) != (B, v.nu, v.T):
+        raise ValueError(f"u must be [B,{v.nu},{v.T}]")
+    xbar = torch.empty((B, 3, v.T + 1), dtype=torch.float64, device=x0.device)
+    _lib.check(lib.mpcx_rollout_batch(C.byref(v), B, _ptr(x0), _ptr(u), _ptr(xbar), _stream()))
+    return xbar
+
+
+def linearize_batch(v: CVariant, theta, u):
+    """get_linear_model_matrix for B operating points: theta [B], u [B,NU] -> A, B, C."""
+    lib = _lib.load()
+    theta = _dev(theta)
+    u = _dev(u)
+    B = theta.shape[0]
+    if tuple(u.shape) != (B, v.nu):
+        raise ValueError(f"u must be [B,{v.nu}]")
+    A = torch.empty((B, 3, 3), dtype=torch.float64, device=theta.device)
+    Bm = torch.empty((B, 3, v.nu), dtype=torch.float64, device=theta.device)
+    Cc = torch.empty((B, 3), dtype=torch.float64, device=theta.device)
+    _lib.check(lib.mpcx_linearize_batch(C.byref(v), B, _ptr(theta), _ptr(u), _ptr(A), _ptr(Bm), _ptr(Cc), _stream()))
+    return A, Bm, Cc
+
+
+class CourseTable:
+    """Padded SoA course tables on the device: cx, cy, cyaw [K, Lmax], clen [K]."""
+
+    def __init__(self, courses):
+        """courses: list of (cx, cy, cyaw) sequences."""
+        K = len(courses)
+        L = max(len(c[0]) for c in courses)
+        tx = np.zeros((K, L))
+        ty = np.zeros((K, L))
+        tw = np.zeros((K, L))
+        ln = np.zeros(K, dtype=np.int32)
+        for k, (cx, cy, cyaw) in enumerate(courses):
+            n = len(cx)
+            tx[k, :n], ty[k, :n], tw[k, :n], ln[k] = cx, cy, cyaw, n
+        self.K, self.Lmax = K, L
+        self.cx, self.cy, self.cyaw = _dev(tx), _dev(ty), _dev(tw)
+        self.clen = _dev(ln, torch.int32)
+        self.clen_host = ln
+
+
+def nearest_ref_batch(mode: int, T: int, dt: float, param: float, state, course_id, pind, table: CourseTable,
+                      n_search: int = 10, sign: bool = True, want_xref: bool = True):
+    """calc_nearest_index + calc_ref_trajectory (mode 0, param = dl) or calc_ref_trajectory2
+    (mode 1, param = n_search_ind).  Returns (ind [B] int32, mind [B], xref [B,3,T+1])."""
+    lib = _lib.load()
+    state = _dev(state)
+    B = state.shape[0]
+    if tuple(state.shape) != (B, 4):
+        raise ValueError("state must be [B,4] = x, y, yaw, vx")
+    course_id = None if course_id is None else _dev(course_id, torch.int32)
+    pind = _dev(pind, torch.int32)
+    ind = torch.empty((B,), dtype=torch.int32, device=state.device)
+    mind = torch.empty((B,), dtype=torch.float64, device=state.device)
+    xref = torch.empty((B, 3, T + 1), dtype=torch.float64, device=state.device) if want_xref else None
+    _lib.check(lib.mpcx_nearest_ref_batch(mode, T, dt, param, n_search, 1 if sign else 0, B, _ptr(state),
+                                          _ptr(course_id), _ptr(pind), _ptr(table.cx), _ptr(table.cy),
+                                          _ptr(table.cyaw), _ptr(table.clen), table.K, table.Lmax,
+                                          _ptr(ind), _ptr(mind), _ptr(xref), _stream()))
+    return ind, mind, xref
