@@ -25,8 +25,9 @@ namespace mpcx {
 constexpr int kWave = 64;
 constexpr double kSlackMin = 1e-16;   // floor on a recomputed slack
 constexpr double kMu0 = 0.1;          // initial complementarity s*lambda
-constexpr double kTolD = 1e-9;        // relative stationarity
-constexpr double kTolMu = 1e-12;      // mean complementarity
+constexpr double kTolD = 1e-8;        // relative stationarity
+constexpr double kTolMu = 1e-11;      // mean complementarity
+constexpr double kMuFloor = 1e-13;    // below this the recomputed slacks are rounding noise: stop
 constexpr double kLooseD = 1e-6;      // "inaccurate but accepted" thresholds
 constexpr double kLooseMu = 1e-7;
 constexpr double kEtaCap = 0.999;
@@ -519,13 +520,14 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
         scale += 1.0;
         const bool conv = rdmax <= kTolD * scale && mu <= kTolMu;
         if (!done && conv) { done = true; status = MPCX_ST_OK; my_iters = it; }
-        if (__all(done) || it >= max_iter) {
-            if (!done) {
-                my_iters = it;
-                status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
-            }
-            break;
+        if (!done && (mu < kMuFloor || it >= max_iter)) {
+            // weakly active constraints make the tail converge linearly; once the barrier
+            // parameter is at the rounding floor further steps only add noise
+            done = true;
+            my_iters = it;
+            status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
         }
+        if (__all(done)) break;
 
         // Cholesky K = L L', right-looking, rinv = 1 / L_ii
 #pragma unroll

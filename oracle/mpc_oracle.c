@@ -412,12 +412,127 @@ static resid_t residuals(const qp_t *q, const int *ip, const int *im, int m, con
     return r;
 }
 
+/* Dense LU with partial pivoting (row-major N x N, in place); returns -1 if singular. */
+static int lu_factor(double *M, int *piv, int N)
+{
+    for (int c = 0; c < N; ++c) {
+        int p = c;
+        double best = fabs(M[c * N + c]);
+        for (int r = c + 1; r < N; ++r)
+            if (fabs(M[r * N + c]) > best) { best = fabs(M[r * N + c]); p = r; }
+        if (!(best > 0.0)) return -1;
+        piv[c] = p;
+        if (p != c)
+            for (int k = 0; k < N; ++k) { double t = M[c * N + k]; M[c * N + k] = M[p * N + k]; M[p * N + k] = t; }
+        double inv = 1.0 / M[c * N + c];
+        for (int r = c + 1; r < N; ++r) {
+            double f = M[r * N + c] * inv;
+            M[r * N + c] = f;
+            if (f != 0.0)
+                for (int k = c + 1; k < N; ++k) M[r * N + k] -= f * M[c * N + k];
+        }
+    }
+    return 0;
+}
+
+static void lu_solve(const double *M, const int *piv, int N, double *b)
+{
+    for (int c = 0; c < N; ++c)   /* whole rows were swapped while factoring: P b first */
+        if (piv[c] != c) { double t = b[c]; b[c] = b[piv[c]]; b[piv[c]] = t; }
+    for (int c = 0; c < N; ++c)
+        for (int r = c + 1; r < N; ++r) b[r] -= M[r * N + c] * b[c];
+    for (int r = N - 1; r >= 0; --r) {
+        double a = b[r];
+        for (int k = r + 1; k < N; ++k) a -= M[r * N + k] * b[k];
+        b[r] = a / M[r * N + r];
+    }
+}
+
+/* Active-set polish of an interior-point answer: equality-constrained QP on the constraints
+ * the iterate marks active (lam_j > s_j), regularised KKT system plus refinement against the
+ * unregularised one.  The iterate is only ~sqrt(mu) accurate on weakly active constraints;
+ * the polished point is exact to rounding.  Accepted only when feasible, dual feasible,
+ * stationary to rounding and close to the iterate; otherwise the iterate is kept. */
+static void polish(const qp_t *q, const int *ip, const int *im, int m, double *w, const double *s,
+                   double *lam)
+{
+    int n = q->n, k = 0;
+    int *act = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
+    for (int j = 0; j < m; ++j) if (lam[j] > s[j]) act[k++] = j;
+    int N = n + k;
+    double *M = (double *)calloc((size_t)N * N, sizeof(double));
+    double *rhs = (double *)malloc(sizeof(double) * N), *sol = (double *)calloc(N, sizeof(double));
+    double *res = (double *)malloc(sizeof(double) * N);
+    int *piv = (int *)malloc(sizeof(int) * N);
+    const double delta = 1e-13;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) M[i * N + j] = q->H[i * n + j];
+    for (int a = 0; a < k; ++a) {
+        int j = act[a];
+        if (ip[j] >= 0) { M[(n + a) * N + ip[j]] = 1.0; M[ip[j] * N + n + a] = 1.0; }
+        if (im[j] >= 0) { M[(n + a) * N + im[j]] = -1.0; M[im[j] * N + n + a] = -1.0; }
+        M[(n + a) * N + n + a] = -delta;
+    }
+    for (int i = 0; i < n; ++i) rhs[i] = -q->g[i];
+    for (int a = 0; a < k; ++a) rhs[n + a] = q->d[act[a]];
+    int ok = lu_factor(M, piv, N) == 0;
+    for (int pass = 0; ok && pass < 4; ++pass) {
+        /* res = rhs - KKT0 * sol (delta = 0) */
+        for (int i = 0; i < n; ++i) {
+            double a = rhs[i];
+            for (int j = 0; j < n; ++j) a -= q->H[i * n + j] * sol[j];
+            res[i] = a;
+        }
+        for (int a = 0; a < k; ++a) {
+            int j = act[a];
+            double nu = sol[n + a];
+            if (ip[j] >= 0) res[ip[j]] -= nu;
+            if (im[j] >= 0) res[im[j]] += nu;
+            res[n + a] = rhs[n + a] - crow(ip, im, j, sol);
+        }
+        lu_solve(M, piv, N, res);
+        for (int i = 0; i < N; ++i) sol[i] += res[i];
+    }
+    for (int i = 0; ok && i < N; ++i) if (!isfinite(sol[i])) ok = 0;
+    if (ok) {
+        double scale = 1.0, stat = 0.0, numin = 0.0, close = 0.0;
+        double *hv = res; /* reuse */
+        for (int i = 0; i < n; ++i) {
+            double a = 0.0;
+            for (int j = 0; j < n; ++j) a += q->H[i * n + j] * sol[j];
+            if (fabs(a) > scale - 1.0) scale = 1.0 + fabs(a);
+            if (fabs(q->g[i]) > scale - 1.0) scale = 1.0 + fabs(q->g[i]);
+            hv[i] = a + q->g[i];
+            if (fabs(sol[i] - w[i]) > close) close = fabs(sol[i] - w[i]);
+        }
+        for (int a = 0; a < k; ++a) {
+            int j = act[a];
+            double nu = sol[n + a];
+            if (nu < numin) numin = nu;
+            if (ip[j] >= 0) hv[ip[j]] += nu;
+            if (im[j] >= 0) hv[im[j]] -= nu;
+        }
+        for (int i = 0; i < n; ++i) if (fabs(hv[i]) > stat) stat = fabs(hv[i]);
+        double viol = -1.0;
+        for (int j = 0; j < m; ++j) { double g = crow(ip, im, j, sol) - q->d[j]; if (g > viol) viol = g; }
+        if (viol <= 1e-12 && numin >= -1e-9 * scale && stat <= 1e-11 * scale && close <= 1e-3) {
+            for (int i = 0; i < n; ++i) w[i] = sol[i];
+            for (int j = 0; j < m; ++j) lam[j] = 0.0;
+            for (int a = 0; a < k; ++a) lam[act[a]] = sol[n + a] > 0.0 ? sol[n + a] : 0.0;
+        }
+    }
+    free(act); free(M); free(rhs); free(sol); free(res); free(piv);
+}
+
+
 /* Mehrotra predictor-corrector; returns iterations, *conv = 1 if the 1e-11 test passed,
  * 0 if only the loose (1e-7) one did, -1 if neither. */
+static int g_polish = 1; /* orc_set_polish(): tests keep it on, the timed CPU baseline turns it off */
+
 static int ipm(const qp_t *q, const int *ip, const int *im, int m, double *w, double *lam_out,
                int *conv, double *kkt)
 {
-    const double tol = 1e-11;
+    const double tol = 1e-10;
     int n = q->n;
     double *K = q->work;
     double *s = K + (size_t)n * n, *lam = s + m, *ds = lam + m, *dl = ds + m;
@@ -428,7 +543,7 @@ static int ipm(const qp_t *q, const int *ip, const int *im, int m, double *w, do
     resid_t r;
     for (it = 1; it <= 80; ++it) {
         r = residuals(q, ip, im, m, w, s, lam, rd, rp);
-        if (r.erd <= tol && r.erp <= tol && r.mu <= 0.1 * tol) { ok = 1; break; }
+        if (r.erd <= tol && r.erp <= tol && r.mu <= 1e-12) { ok = 1; break; }
         if (r.mu < 1e-16) break;
         memcpy(K, q->H, sizeof(double) * n * n);
         for (int j = 0; j < m; ++j) {
@@ -478,6 +593,10 @@ static int ipm(const qp_t *q, const int *ip, const int *im, int m, double *w, do
         ok = (r.erd <= 1e-7 && r.erp <= 1e-7 && r.mu <= 1e-7) ? 0 : -1;
     }
     *conv = ok;
+    if (ok >= 0 && g_polish && m > 0) {
+        polish(q, ip, im, m, w, s, lam);
+        r = residuals(q, ip, im, m, w, s, lam, rd, rp);
+    }
     if (kkt) {
         /* certificate of what is returned: relative stationarity, violation, complementarity */
         double viol = 0.0, comp = 0.0;
@@ -776,3 +895,5 @@ int orc_nearest_ref_batch(int mode, int T, double dt, double param, int n_search
 }
 
 int orc_variant_size(void) { return (int)sizeof(orc_variant); }
+
+void orc_set_polish(int on) { g_polish = on; }

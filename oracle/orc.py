@@ -51,6 +51,12 @@ def lib():
     return _lib
 
 
+def set_polish(on: bool):
+    """Active-set polish after the interior-point solve (default on; the timed CPU baseline
+    turns it off so the baseline is not charged for the checker's extra accuracy)."""
+    lib().orc_set_polish(C.c_int(1 if on else 0))
+
+
 def _pad4(t, fill=0.0):
     t = tuple(t)
     return t + (fill,) * (4 - len(t))

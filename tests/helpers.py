@@ -1,0 +1,55 @@
+"""Shared helpers of the parity tests (test infrastructure)."""
+import numpy as np
+
+from oracle import mpc_oracle as O
+
+# parity bars stated by the task: controls 1e-3 absolute, objective 1e-4 relative.
+U_BAR = 1e-3
+OBJ_BAR = 1e-4
+# what the engine is actually held to against the oracle (both solve the same strictly
+# convex QP; the residual gap is the interior-point stopping tolerance on weakly active
+# constraints)
+U_TIGHT = 2e-4
+OBJ_TIGHT = 1e-5
+
+
+def make_problem(name, B, seed=7, n_courses=16, **overrides):
+    """(product variant, oracle variant, x0 [B,3], xref [B,3,T+1]) on spline courses."""
+    from model_predictive_control_amd import variants, workload
+    v = variants.get(name, **overrides)
+    ov = O.variant(name, **overrides)
+    courses = workload.make_courses(n_courses)
+    inst = workload.make_instances(courses, B, seed=seed)
+    if name == "mpc_py":
+        # mpc.py takes the next HL+1 course points as reference (mpc.py:292-296)
+        xref = np.empty((B, 3, v.T + 1))
+        for b in range(B):
+            cx, cy, cyaw = courses[inst["course_id"][b]]
+            p = int(inst["pind"][b])
+            idx = np.minimum(p + 3 * np.arange(v.T + 1), len(cx) - 1)
+            xref[b] = np.stack([cx[idx], cy[idx], cyaw[idx]])
+    else:
+        xref = workload.reference_window(courses, inst, v.T)
+    return v, ov, inst["state"][:, :3].copy(), xref
+
+
+def compare(out, ref, u_tol=U_TIGHT, obj_tol=OBJ_TIGHT, x_tol=U_TIGHT):
+    """Asserts statuses agree and solutions match; returns the worst deviations."""
+    st = out["status"].cpu().numpy()
+    u = out["u"].cpu().numpy()
+    x = out["x"].cpu().numpy()
+    obj = out["obj"].cpu().numpy()
+    good_ref = ref["status"] <= 1
+    good_gpu = st <= 1
+    assert np.array_equal(good_ref, good_gpu), (np.bincount(st, minlength=5), np.bincount(ref["status"], minlength=5))
+    bad = ~good_ref
+    assert np.array_equal(st[bad], ref["status"][bad])
+    assert np.isnan(u[bad]).all() and np.isnan(obj[bad]).all()
+    g = good_ref
+    du = np.abs(u[g] - ref["u"][g]).max() if g.any() else 0.0
+    dx = np.abs(x[g] - ref["x"][g]).max() if g.any() else 0.0
+    dobj = (np.abs(obj[g] - ref["obj"][g]) / np.maximum(1.0, np.abs(ref["obj"][g]))).max() if g.any() else 0.0
+    assert du <= u_tol, f"controls differ by {du}"
+    assert dx <= x_tol, f"states differ by {dx}"
+    assert dobj <= obj_tol, f"objective differs by {dobj} (relative)"
+    return du, dx, dobj

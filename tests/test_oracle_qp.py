@@ -1,0 +1,111 @@
+"""The QP part of the oracle has no reference fixture to be pinned by (the reference
+solves through cvxpy/ECOS, absent here): PARITY UNPINNED.  What these tests establish
+instead: three independent solvers (interior point in numpy, interior point in C,
+textbook active set, plus scipy's SLSQP) agree on the unique minimiser, and the KKT
+certificate of the returned point holds."""
+import numpy as np
+import pytest
+from scipy.optimize import LinearConstraint, minimize
+
+from oracle import mpc_oracle as O
+from oracle import orc
+from tests.helpers import make_problem
+
+NAMES = ["diff_drive", "dsr_ackermann", "dsr_crab", "dsr_diff", "sim_ackermann", "sim_diff", "sim_crab", "mpc_py"]
+
+
+def _instances(name, n, **kw):
+    from model_predictive_control_amd import workload
+    ov = O.variant(name, **kw)
+    courses = workload.make_courses(4, seed=5)
+    inst = workload.make_instances(courses, n, seed=9)
+    xref = workload.reference_window(courses, inst, ov.T)
+    return ov, inst["state"][:, :3], xref
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_ipm_active_set_scipy_agree(name):
+    ov, x0, xref = _instances(name, 6, chain=1)
+    for b in range(6):
+        r = O.iterative_linear_mpc_control(ov, xref[b], x0[b], None)
+        if b % 2:
+            r = O.iterative_linear_mpc_control(ov, xref[b], x0[b], r.u)
+        assert r.status == O.ST_OK
+        Cm, d = O.constraint_rows(r.qp.lo, r.qp.hi, r.qp.rr)
+        stat, viol, neg, comp = O.kkt_residuals(r.qp.H, r.qp.g, Cm, d, r.w, r.lam)
+        assert stat < 1e-8 and viol < 1e-10 and neg < 1e-12 and comp < 1e-9
+        w_as, lam_as = O.solve_qp_active_set(r.qp.H, r.qp.g, Cm, d)
+        assert np.abs(w_as - r.w).max() < 2e-6
+        f = lambda w: 0.5 * w @ r.qp.H @ w + r.qp.g @ w
+        res = minimize(f, w_as * 0.0 + O._feasible_point(Cm, d, r.w.size), jac=lambda w: r.qp.H @ w + r.qp.g,
+                       constraints=[LinearConstraint(Cm, -np.inf, d)], method="SLSQP",
+                       options=dict(ftol=1e-14, maxiter=500))
+        assert abs(res.fun - f(r.w)) <= 1e-8 * max(1.0, abs(f(r.w)))
+        assert np.abs(res.x - r.w).max() < 5e-4
+        # the objective the engine reports is the reference's cost expression, constants included
+        assert abs(r.obj - (f(r.w) + r.qp.c0)) <= 1e-9 * max(1.0, abs(r.obj))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_c_restatement_matches_numpy_twin(name):
+    ov, x0, xref = _instances(name, 24)
+    ref = [O.iterative_linear_mpc_control(ov, xref[b], x0[b], None) for b in range(24)]
+    out = orc.iterative_batch(ov, x0, xref)
+    # two interior-point runs stop at slightly different points: ~sqrt(mu) = 1e-6 on weakly
+    # active constraints; chained solves re-linearise at the previous answer
+    tol = 1e-5 if ov.chain > 1 else 1e-6
+    for b in range(24):
+        assert out["status"][b] == ref[b].status == O.ST_OK
+        assert np.abs(out["u"][b] - ref[b].u).max() < tol
+        assert np.abs(out["x"][b] - ref[b].x).max() < tol
+        assert abs(out["obj"][b] - ref[b].obj) <= 1e-9 * max(1.0, abs(ref[b].obj))
+    assert out["kkt"].max() < 1e-9
+    up = np.stack([r.u for r in ref])
+    out2 = orc.iterative_batch(ov, x0, xref, up, (np.arange(24) % 2).astype(np.uint8))
+    for b in range(24):
+        r = O.iterative_linear_mpc_control(ov, xref[b], x0[b], up[b] if b % 2 else None)
+        assert np.abs(out2["u"][b] - r.u).max() < tol
+
+
+def test_chain_is_the_literal_mpc_sim_loop():
+    """Re-enacts mpc_sim.py:292-308 step by step with single QPs and compares with chain=5."""
+    ov = O.variant("sim_ackermann")
+    one = O.variant("sim_ackermann", chain=1)
+    _, x0, xref = _instances("sim_ackermann", 3)
+    for b in range(3):
+        prev = O.iterative_linear_mpc_control(one, xref[b], x0[b], None).u
+        xbar = O.rollout(ov, x0[b], prev)
+        uref = np.zeros((4, 5))
+        cur = prev
+        for i in range(5):
+            uref[:, i] = cur[:, i]
+            cur = O.linear_mpc_control(one, xref[b], xbar, x0[b], uref).u
+        got = O.iterative_linear_mpc_control(ov, xref[b], x0[b], prev)
+        assert np.abs(got.u - cur).max() < 1e-12
+
+
+def test_infeasible_first_step_window():
+    ov = O.variant("dsr_ackermann")
+    xref = np.zeros((3, 6))
+    uref = np.zeros((4, 5))
+    uref[1, 0], uref[3, 0] = 0.2, 0.9
+    r = O.linear_mpc_control(ov, xref, np.zeros((3, 6)), [0, 0, 0], uref)
+    assert r.status == O.ST_INFEASIBLE and r.u is None
+    out = orc.linear_mpc_batch(ov, xref[None], np.zeros((1, 3, 6)), np.zeros((1, 3)), uref[None])
+    assert out["status"][0] == O.ST_INFEASIBLE and np.isnan(out["u"]).all()
+    uref[3, 0] = -0.2
+    assert O.linear_mpc_control(ov, xref, np.zeros((3, 6)), [0, 0, 0], uref).status == O.ST_OK
+
+
+def test_survey_measured_first_tick():
+    cx, cy, cyaw = O.make_eight_shape_trajectory(400, 10)
+    x0 = [cx[0], cy[0], cyaw[0]]
+    cx.pop(0); cy.pop(0); cyaw.pop(0)
+    O.smooth_yaw(cyaw)
+    xref, ind = O.calc_ref_trajectory2(5, x0[0], x0[1], cx, cy, cyaw, 2, 0)
+    r = O.iterative_linear_mpc_control(O.variant("diff_drive"), xref, x0, None)
+    np.testing.assert_allclose(r.u[0], 0.47, atol=1e-9)
+    np.testing.assert_allclose(r.u[1], [3.32808e-2, 7.04498e-3, 2.46821e-4, -1.29074e-3, -1.22695e-3], atol=2e-7)
+    assert abs(r.obj - 14.2530216) < 1e-6
+    ev = np.linalg.eigvalsh(r.qp.H)
+    assert abs(ev[0] - 0.0309) < 1e-3 and abs(ev[-1] - 1.007) < 1e-2
