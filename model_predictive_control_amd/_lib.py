@@ -59,6 +59,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  (first, so libmpcx.so binds to the HIP runtime torch ships, not a second one)
     if not os.path.exists(LIB_PATH):
         raise MpcxError(
             f"{LIB_PATH} is missing: build it with `python -m model_predictive_control_amd.build` "

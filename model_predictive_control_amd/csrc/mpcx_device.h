@@ -406,6 +406,48 @@ __device__ __forceinline__ void assemble(S &s, const mpcx_variant &v, const doub
     s.finishH();
 }
 
+// Cholesky K = L L' in place (right-looking), rinv = 1 / L_ii.
+template <class S>
+__device__ __forceinline__ void chol_factor(S &s)
+{
+    const int N = 2 * s.horizon();
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double r = rsqrt_nr(s.K(j, j));
+        s.rinv(j) = r;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) s.K(i, j) *= r;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            const double lij = s.K(i, j);
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) s.K(i, k) = fma(-lij, s.K(k, j), s.K(i, k));
+        }
+    }
+}
+
+// vec <- K^-1 vec with the factor above; vec(i) returns a reference.
+template <class S, class V>
+__device__ __forceinline__ void chol_apply(S &s, V &&vec)
+{
+    const int N = 2 * s.horizon();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double a = vec(i);
+#pragma unroll
+        for (int k = 0; k < i; ++k) a = fma(-s.K(i, k), vec(k), a);
+        vec(i) = a * s.rinv(i);
+    }
+#pragma unroll
+    for (int ii = 0; ii < N; ++ii) {
+        const int i = N - 1 - ii;
+        double a = vec(i);
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) a = fma(-s.K(k, i), vec(k), a);
+        vec(i) = a * s.rinv(i);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // interior point solve of  min 1/2 w'Hw + g'w,  lo <= w <= hi,  |w[i+2]-w[i]| <= rr[i&1]
 // ------------------------------------------------------------------------------------
@@ -529,37 +571,8 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
         }
         if (__all(done)) break;
 
-        // Cholesky K = L L', right-looking, rinv = 1 / L_ii
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const double r = rsqrt_nr(s.K(j, j));
-            s.rinv(j) = r;
-#pragma unroll
-            for (int i = j + 1; i < N; ++i) s.K(i, j) *= r;
-#pragma unroll
-            for (int i = j + 1; i < N; ++i) {
-                const double lij = s.K(i, j);
-#pragma unroll
-                for (int k = j + 1; k <= i; ++k) s.K(i, k) = fma(-lij, s.K(k, j), s.K(i, k));
-            }
-        }
-        auto chol_solve = [&](auto &&vec) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                double a = vec(i);
-#pragma unroll
-                for (int k = 0; k < i; ++k) a = fma(-s.K(i, k), vec(k), a);
-                vec(i) = a * s.rinv(i);
-            }
-#pragma unroll
-            for (int ii = 0; ii < N; ++ii) {
-                const int i = N - 1 - ii;
-                double a = vec(i);
-#pragma unroll
-                for (int k = i + 1; k < N; ++k) a = fma(-s.K(k, i), vec(k), a);
-                vec(i) = a * s.rinv(i);
-            }
-        };
+        chol_factor(s);
+        auto chol_solve = [&](auto &&vec) { chol_apply(s, vec); };
 
         // predictor: (H + C'DC) dwa = -(Hw + g)
 #pragma unroll
@@ -698,6 +711,158 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
         }
     }
     iters = my_iters;
+}
+
+// ------------------------------------------------------------------------------------
+// Active-set polish.  The interior-point iterate is only ~sqrt(mu) accurate on weakly
+// active constraints; here the constraints it marks active (lambda_j > s_j) are imposed as
+// equalities and the equality-constrained QP is solved by three augmented-Lagrangian Newton
+// steps that share one Cholesky factor of K = H + rho * A_act' A_act.  Residuals are formed
+// with the true H, so the fixed point is the exact KKT point whatever the accuracy of the
+// factor.  The polished point replaces the iterate only if it is feasible for every
+// constraint, its multipliers are non-negative and it is stationary to rounding.
+// Returns true when accepted.
+// ------------------------------------------------------------------------------------
+template <bool ALL, class S>
+__device__ __forceinline__ bool polish(S &s, const FreeBounds &fb)
+{
+    const int T = s.horizon(), N = 2 * T, NR = N - 2;
+    const bool bx[2] = {ALL || fb.box[0], ALL || fb.box[1]};
+    const bool bx0[2] = {ALL || fb.box0[0], ALL || fb.box0[1]};
+    const bool rt[2] = {ALL || fb.rate[0], ALL || fb.rate[1]};
+    auto hasbox = [&](int i) { return (i >> 1) == 0 ? bx0[i & 1] : bx[i & 1]; };
+    auto hi_of = [&](int i) { return (i >> 1) == 0 ? fb.hi0[i & 1] : fb.b[i & 1]; };
+    auto lo_of = [&](int i) { return (i >> 1) == 0 ? fb.lo0[i & 1] : -fb.b[i & 1]; };
+
+    // active flags (kept as 0/1 in the reciprocal-slack arrays), multipliers of the rest zeroed
+    double hmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        hmax = dmax(hmax, s.H(i, i));
+        s.dwa(i) = s.w(i);   // backup of the interior-point iterate
+        double au = 0.0, al = 0.0;
+        if (hasbox(i)) {
+            const double wi = s.w(i);
+            au = s.lamU(i) > hi_of(i) - wi ? 1.0 : 0.0;
+            al = s.lamL(i) > wi - lo_of(i) ? 1.0 : 0.0;
+        }
+        s.isu(i) = au; s.isl(i) = al;
+        s.lamU(i) = au * s.lamU(i);
+        s.lamL(i) = al * s.lamL(i);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        double au = 0.0, al = 0.0;
+        if (rt[i & 1]) {
+            const double rr = fb.rr[i & 1], dv = s.w(i + 2) - s.w(i);
+            au = s.nuU(i) > rr - dv ? 1.0 : 0.0;
+            al = s.nuL(i) > rr + dv ? 1.0 : 0.0;
+        }
+        s.iru(i) = au; s.irl(i) = al;
+        s.nuU(i) = au * s.nuU(i);
+        s.nuL(i) = al * s.nuL(i);
+    }
+    const double rho = 1e5 * hmax;
+
+    // K = H + rho A'A on the active rows, one factorisation
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int j = 0; j < i; ++j) s.K(i, j) = s.H(i, j);
+        s.K(i, i) = fma(rho, s.isu(i) + s.isl(i), s.H(i, i));
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const double d = rho * (s.iru(i) + s.irl(i));
+        s.K(i, i) += d;
+        s.K(i + 2, i + 2) += d;
+        s.K(i + 2, i) -= d;
+    }
+    chol_factor(s);
+
+    double stat = 0.0, scale = 1.0;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        // hw = H w + g
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.hw(i) = s.g(i);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double wi = s.w(i);
+            double acc = s.hw(i);
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                const double h = s.H(i, j);
+                acc = fma(h, s.w(j), acc);
+                s.hw(j) = fma(h, wi, s.hw(j));
+            }
+            s.hw(i) = fma(s.H(i, i), wi, acc);
+        }
+        // multiplier update with the constraint values at the current point (skipped on the
+        // first pass), then gradient of the Lagrangian (dw) and of the augmented one (hw)
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.dw(i) = s.hw(i);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double wi = s.w(i);
+            const double cu = s.isu(i) * (wi - hi_of(i)), cl = s.isl(i) * (lo_of(i) - wi);
+            if (pass > 0) { s.lamU(i) = fma(rho, cu, s.lamU(i)); s.lamL(i) = fma(rho, cl, s.lamL(i)); }
+            const double t = s.lamU(i) - s.lamL(i);
+            s.dw(i) += t;
+            s.hw(i) += t + rho * (cu - cl);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const double rr = fb.rr[i & 1], dv = s.w(i + 2) - s.w(i);
+            const double cu = s.iru(i) * (dv - rr), cl = s.irl(i) * (-dv - rr);
+            if (pass > 0) { s.nuU(i) = fma(rho, cu, s.nuU(i)); s.nuL(i) = fma(rho, cl, s.nuL(i)); }
+            const double t = s.nuU(i) - s.nuL(i);
+            s.dw(i + 2) += t; s.dw(i) -= t;
+            const double ta = t + rho * (cu - cl);
+            s.hw(i + 2) += ta; s.hw(i) -= ta;
+        }
+        stat = 0.0; scale = 1.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            stat = dmax(stat, fabs(s.dw(i)));
+            scale = dmax(scale, dmax(fabs(s.g(i)), fabs(s.dw(i) - s.hw(i))));
+        }
+        if (pass == 3) break;
+        // Newton step on the augmented Lagrangian
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.hw(i) = -s.hw(i);
+        chol_apply(s, [&](int i) -> double & { return s.hw(i); });
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.w(i) += s.hw(i);
+    }
+    // acceptance: stationary, every constraint satisfied, multipliers non-negative, close by
+    double viol = 0.0, neg = 0.0, far = 0.0, cact = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double wi = s.w(i);
+        far = dmax(far, fabs(wi - s.dwa(i)));
+        if (hasbox(i)) {
+            viol = dmax(viol, dmax(wi - hi_of(i), lo_of(i) - wi));
+            cact = dmax(cact, dmax(s.isu(i) * fabs(wi - hi_of(i)), s.isl(i) * fabs(lo_of(i) - wi)));
+        }
+        neg = dmax(neg, dmax(-s.lamU(i), -s.lamL(i)));
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        if (rt[i & 1]) {
+            const double rr = fb.rr[i & 1], dv = s.w(i + 2) - s.w(i);
+            viol = dmax(viol, dmax(dv - rr, -dv - rr));
+            cact = dmax(cact, dmax(s.iru(i) * fabs(dv - rr), s.irl(i) * fabs(-dv - rr)));
+        }
+        neg = dmax(neg, dmax(-s.nuU(i), -s.nuL(i)));
+    }
+    scale += 1.0;
+    const bool ok = stat <= 1e-10 * scale && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale && far <= 1e-3;
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.w(i) = s.dwa(i);
+    }
+    return ok;
 }
 
 }  // namespace mpcx

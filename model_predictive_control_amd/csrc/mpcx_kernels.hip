@@ -122,6 +122,8 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
             status = st;
             if (st == MPCX_ST_FAILED) skip = true;
         }
+        const bool polished = polish<ALL>(s, fb);
+        if (!skip && polished) status = MPCX_ST_OK;
     }
 
     // controls, predicted states, objective (cost expression of mpc_diff_drive.py:178-193
