@@ -3,7 +3,7 @@
 // One MPC instance = one lane.  The same templates serve two storage policies:
 //   RegStore<T>  every per-instance array is a local array with compile-time
 //                indices after full unrolling (VGPR/AGPR resident); the
-//                condensed Hessian sits in LDS as [element][lane];
+//                condensed Hessian and gradient sit in LDS as [element][lane];
 //   MemStore     runtime horizon; arrays live in a global workspace laid out
 //                [element][instance] so a wavefront's accesses coalesce.
 //
@@ -21,6 +21,12 @@
 #include "mpcx.h"
 
 namespace mpcx {
+
+#ifdef MPCX_MARK_PHASES
+#define MPCX_PHASE(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; PHASE " name ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MPCX_PHASE(name)
+#endif
 
 constexpr int kWave = 64;
 constexpr double kSlackMin = 1e-16;   // floor on a recomputed slack
@@ -50,7 +56,46 @@ __device__ __forceinline__ double rsqrt_nr(double x)
     r = fma(0.5 * r, e, r);
     return r;
 }
+// Returns x, but the compiler may not assume so: used where a cheap value is deliberately
+// recomputed in a later phase instead of being kept in registers across a factorisation
+// (common-subexpression elimination would otherwise undo that and spill).
+__device__ __forceinline__ double opaque(double x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ bool finite_d(double x) { return fabs(x) <= 1.79769313486231570e308; }
+
+// sin and cos together: three-constant Cody-Waite reduction by pi/2 with fused
+// multiply-adds (each product is exact inside its fma and the running remainder stays
+// below 1, so the reduced argument carries an absolute error near 1e-16 for any |x| whose
+// quadrant count is still an exact double, far beyond any yaw or steer angle), then the
+// classic degree-13/14 minimax kernels on [-pi/4, pi/4] (fdlibm's __kernel_sin /
+// __kernel_cos coefficients): about one ulp.  Branch-free; NaN/Inf in gives NaN out.
+__device__ __forceinline__ void sincos_fast(double x, double &sn, double &cs)
+{
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632679489655800e+00, x);
+    r = fma(-k, 6.12323399573676603587e-17, r);
+    r = fma(-k, -1.49738490485919873423e-33, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s0 = fma(z * r, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)(long long)k;
+    const double sa = (q & 1) ? c0 : s0, ca = (q & 1) ? s0 : c0;
+    sn = (q & 2) ? -sa : sa;
+    cs = ((q + 1) & 2) ? -ca : ca;
+}
 
 // ------------------------------------------------------------------------------------
 // models
@@ -69,7 +114,7 @@ __device__ __forceinline__ void linearize(const mpcx_variant &v, double th, cons
 {
     const double dt = v.dt;
     double st, ct;
-    sincos(th, &st, &ct);
+    sincos_fast(th, st, ct);
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -88,8 +133,8 @@ __device__ __forceinline__ void linearize(const mpcx_variant &v, double th, cons
     } else {
         const double v_f = u[0], d_f = u[1], v_r = u[2], d_r = u[3];
         double sf, cf, sr, cr;
-        sincos(d_f, &sf, &cf);
-        sincos(d_r, &sr, &cr);
+        sincos_fast(d_f, sf, cf);
+        sincos_fast(d_r, sr, cr);
         const double h = 0.5 * dt, k = 1.0 / v.wb * dt;
         const double vc = v_f * cf + v_r * cr, vs = v_f * sf + v_r * sr;
         a02 = -0.5 * dt * vc * st - 0.5 * dt * vs * ct;
@@ -120,7 +165,7 @@ __device__ __forceinline__ void plant_step(const mpcx_variant &v, double &x, dou
                                            const double (&u)[4])
 {
     double s, c;
-    sincos(yaw, &s, &c);
+    sincos_fast(yaw, s, c);
     const double dt = v.dt;
     if (MODEL == MPCX_MODEL_DIFF_DRIVE) {
         x = x + u[0] * c * dt;
@@ -128,8 +173,8 @@ __device__ __forceinline__ void plant_step(const mpcx_variant &v, double &x, dou
         yaw = yaw + u[1] * dt;
     } else {
         double sf, cf, sr, cr;
-        sincos(u[1], &sf, &cf);
-        sincos(u[3], &sr, &cr);
+        sincos_fast(u[1], sf, cf);
+        sincos_fast(u[3], sr, cr);
         const double v1x = cf * u[0], v1y = sf * u[0], v2x = cr * u[2], v2y = sr * u[2];
         const double vx = 0.5 * (v1x + v2x), vy = 0.5 * (v1y + v2y), w = (v1y - v2y) / v.wb;
         x = x + vx * c * dt - vy * s * dt;
@@ -143,7 +188,10 @@ template <int MODEL>
 __device__ __forceinline__ double yaw_rate(const mpcx_variant &v, const double (&u)[4])
 {
     if (MODEL == MPCX_MODEL_DIFF_DRIVE) return u[1];
-    return (sin(u[1]) * u[0] - sin(u[3]) * u[2]) / v.wb;
+    double sf, cf, sr, cr;
+    sincos_fast(u[1], sf, cf);
+    sincos_fast(u[3], sr, cr);
+    return (sf * u[0] - sr * u[2]) / v.wb;
 }
 
 // ------------------------------------------------------------------------------------
@@ -157,8 +205,8 @@ struct FreeBounds {
     bool feasible;
 };
 
-__device__ __forceinline__ double dmin(double a, double b) { return a < b ? a : b; }
-__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }
+__device__ __forceinline__ double dmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double dmax(double a, double b) { return __builtin_fmax(a, b); }
 
 // uref0: first column of uref (all NU rows; unused rows ignored).
 __device__ __forceinline__ void free_bounds(const mpcx_variant &v, const double (&u0)[4], FreeBounds &fb)
@@ -213,62 +261,68 @@ __device__ __forceinline__ void free_bounds(const mpcx_variant &v, const double 
 // ------------------------------------------------------------------------------------
 template <int T_>
 struct RegStore {
-    static constexpr bool kStatic = true;
     static constexpr int T = T_, N = 2 * T_, NT = N * (N + 1) / 2;
+    static constexpr int kLdsDoubles = NT + N;   // per lane: H (packed lower) then g
     double K_[NT];
     double G_[3 * N], g_[N], w_[N], lamU_[N], lamL_[N], nuU_[N], nuL_[N];
-    double hw_[N], dwa_[N], dw_[N], rinv_[N], isu_[N], isl_[N], iru_[N], irl_[N];
-    double sa02_[T], sa12_[T], sb_[6 * T], sc_[3 * T], theta_[T], uref_[4 * T];
-    double *Hs;   // LDS, [NT][64], already offset by the lane
+    double dwa_[N], dw_[N];
+    // reciprocal slacks, later dual steps, in the polish 0/1 flags: single precision is enough
+    // (every use is consistent with the rounded value, so it only perturbs the Newton step)
+    // and it halves their registers
+    typedef float aux_t;
+    aux_t isu_[N], isl_[N], iru_[N], irl_[N];
+    double theta_[T], uref_[4 * T];   // only live in the chained (mpc_sim) instantiation
+    typedef __attribute__((address_space(3))) double lds_double;
+    lds_double *Hs;                   // LDS, [NT + N][64], already offset by the lane
     __device__ __forceinline__ int horizon() const { return T; }
     __device__ __forceinline__ static int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+    // assembly accumulates H in the registers K will use, g in registers, then parks both in LDS
     __device__ __forceinline__ double &Hacc(int i, int j) { return K_[tri(i, j)]; }
-    __device__ __forceinline__ void finishH()
+    __device__ __forceinline__ double &gacc(int i) { return g_[i]; }
+    __device__ __forceinline__ void finish_assembly()
     {
 #pragma unroll
         for (int e = 0; e < NT; ++e) Hs[e * kWave] = K_[e];
+#pragma unroll
+        for (int i = 0; i < N; ++i) Hs[(NT + i) * kWave] = g_[i];
     }
-    __device__ __forceinline__ double H(int i, int j) const { return Hs[tri(i, j) * kWave]; }
+    // volatile: H and g must be re-read from LDS where they are used; a plain load is loop
+    // invariant, gets hoisted out of the solver loop and takes 130 registers with it
+    __device__ __forceinline__ double H(int i, int j) const { return ((const volatile lds_double *)Hs)[tri(i, j) * kWave]; }
+    __device__ __forceinline__ double g(int i) const { return ((const volatile lds_double *)Hs)[(NT + i) * kWave]; }
     __device__ __forceinline__ double &K(int i, int j) { return K_[tri(i, j)]; }
     __device__ __forceinline__ double &G(int r, int j) { return G_[r * N + j]; }
-    __device__ __forceinline__ double &g(int i) { return g_[i]; }
     __device__ __forceinline__ double &w(int i) { return w_[i]; }
     __device__ __forceinline__ double &lamU(int i) { return lamU_[i]; }
     __device__ __forceinline__ double &lamL(int i) { return lamL_[i]; }
     __device__ __forceinline__ double &nuU(int i) { return nuU_[i]; }
     __device__ __forceinline__ double &nuL(int i) { return nuL_[i]; }
-    __device__ __forceinline__ double &hw(int i) { return hw_[i]; }
+    // hw (= H w + g) and dwa (predictor step) share storage: the predictor solve runs in place
+    __device__ __forceinline__ double &hw(int i) { return dwa_[i]; }
     __device__ __forceinline__ double &dwa(int i) { return dwa_[i]; }
     __device__ __forceinline__ double &dw(int i) { return dw_[i]; }
-    __device__ __forceinline__ double &rinv(int i) { return rinv_[i]; }
-    __device__ __forceinline__ double &isu(int i) { return isu_[i]; }
-    __device__ __forceinline__ double &isl(int i) { return isl_[i]; }
-    __device__ __forceinline__ double &iru(int i) { return iru_[i]; }
-    __device__ __forceinline__ double &irl(int i) { return irl_[i]; }
-    __device__ __forceinline__ double &sa02(int t) { return sa02_[t]; }
-    __device__ __forceinline__ double &sa12(int t) { return sa12_[t]; }
-    __device__ __forceinline__ double &sb(int t, int k) { return sb_[6 * t + k]; }
-    __device__ __forceinline__ double &sc(int t, int r) { return sc_[3 * t + r]; }
+    __device__ __forceinline__ aux_t &isu(int i) { return isu_[i]; }
+    __device__ __forceinline__ aux_t &isl(int i) { return isl_[i]; }
+    __device__ __forceinline__ aux_t &iru(int i) { return iru_[i]; }
+    __device__ __forceinline__ aux_t &irl(int i) { return irl_[i]; }
     __device__ __forceinline__ double &theta(int t) { return theta_[t]; }
     __device__ __forceinline__ double &uref(int r, int t) { return uref_[r * T + t]; }
 };
 
 struct MemStore {
-    static constexpr bool kStatic = false;
+    typedef double aux_t;
     int T, N, NT;
-    double *base;    // workspace + instance index
-    int64_t stride;  // padded batch
-    int oH, oK, oG, og, ow, olU, olL, onU, onL, ohw, odwa, odw, orinv, oisu, oisl, oiru, oirl;
-    int osa02, osa12, osb, osc, oth, ouref, total;
+    double *base;    // workspace + slot index
+    int64_t stride;  // slots per element row
+    int oH, oK, oG, og, ow, olU, olL, onU, onL, ohw, odwa, odw, oisu, oisl, oiru, oirl, oth, ouref, total;
     __host__ __device__ void layout(int T_)
     {
         T = T_; N = 2 * T_; NT = N * (N + 1) / 2;
         int o = 0;
         oH = o; o += NT; oK = o; o += NT; oG = o; o += 3 * N;
         og = o; o += N; ow = o; o += N; olU = o; o += N; olL = o; o += N; onU = o; o += N; onL = o; o += N;
-        ohw = o; o += N; odwa = o; o += N; odw = o; o += N; orinv = o; o += N;
+        ohw = o; odwa = o; o += N; odw = o; o += N;   // hw and dwa share storage
         oisu = o; o += N; oisl = o; o += N; oiru = o; o += N; oirl = o; o += N;
-        osa02 = o; o += T; osa12 = o; o += T; osb = o; o += 6 * T; osc = o; o += 3 * T;
         oth = o; o += T; ouref = o; o += 4 * T;
         total = o;
     }
@@ -276,11 +330,12 @@ struct MemStore {
     __device__ __forceinline__ static int tri(int i, int j) { return i * (i + 1) / 2 + j; }
     __device__ __forceinline__ double &at(int o) { return base[(int64_t)o * stride]; }
     __device__ __forceinline__ double &Hacc(int i, int j) { return at(oH + tri(i, j)); }
-    __device__ __forceinline__ void finishH() {}
+    __device__ __forceinline__ double &gacc(int i) { return at(og + i); }
+    __device__ __forceinline__ void finish_assembly() {}
     __device__ __forceinline__ double H(int i, int j) { return at(oH + tri(i, j)); }
+    __device__ __forceinline__ double g(int i) { return at(og + i); }
     __device__ __forceinline__ double &K(int i, int j) { return at(oK + tri(i, j)); }
     __device__ __forceinline__ double &G(int r, int j) { return at(oG + r * N + j); }
-    __device__ __forceinline__ double &g(int i) { return at(og + i); }
     __device__ __forceinline__ double &w(int i) { return at(ow + i); }
     __device__ __forceinline__ double &lamU(int i) { return at(olU + i); }
     __device__ __forceinline__ double &lamL(int i) { return at(olL + i); }
@@ -289,18 +344,60 @@ struct MemStore {
     __device__ __forceinline__ double &hw(int i) { return at(ohw + i); }
     __device__ __forceinline__ double &dwa(int i) { return at(odwa + i); }
     __device__ __forceinline__ double &dw(int i) { return at(odw + i); }
-    __device__ __forceinline__ double &rinv(int i) { return at(orinv + i); }
     __device__ __forceinline__ double &isu(int i) { return at(oisu + i); }
     __device__ __forceinline__ double &isl(int i) { return at(oisl + i); }
     __device__ __forceinline__ double &iru(int i) { return at(oiru + i); }
     __device__ __forceinline__ double &irl(int i) { return at(oirl + i); }
-    __device__ __forceinline__ double &sa02(int t) { return at(osa02 + t); }
-    __device__ __forceinline__ double &sa12(int t) { return at(osa12 + t); }
-    __device__ __forceinline__ double &sb(int t, int k) { return at(osb + 6 * t + k); }
-    __device__ __forceinline__ double &sc(int t, int r) { return at(osc + 3 * t + r); }
     __device__ __forceinline__ double &theta(int t) { return at(oth + t); }
     __device__ __forceinline__ double &uref(int r, int t) { return at(ouref + r * T + t); }
 };
+
+// ------------------------------------------------------------------------------------
+// linearisation point: where the controls uref[:, t] and the yaw xbar[2][t] come from.
+//   STORED = false  straight from the caller's buffers (or the cold-start constants), yaw
+//                   either read from xbar or rolled forward from x0 with predict_motion's
+//                   yaw update; nothing is kept in registers, the epilogue re-reads it;
+//   STORED = true   from the store's uref/theta arrays (chained solves rewrite uref between
+//                   passes; the memory-resident path always uses this).
+// ------------------------------------------------------------------------------------
+struct LinPoint {
+    const double *u;      // [NU][T] of this instance, or nullptr -> cold start
+    const double *yaw;    // xbar[2][0..T-1] of this instance, or nullptr -> roll from theta0
+    const double *cold;   // v.cold_start
+    double theta0;
+};
+
+// One stage: controls and yaw -> reduced dynamics  x+ = A x + bt w_t + ct  with
+// A = I + a02 e0 e2' + a12 e1 e2'.  `th` carries the rolled yaw from stage to stage.
+template <int MODEL, bool STORED, class S>
+__device__ __forceinline__ void stage_dynamics(S &s, const mpcx_variant &v, const LinPoint &lp, int t,
+                                               double &th, double &a02, double &a12, double (&bt)[3][2],
+                                               double (&ct)[3])
+{
+    constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
+    const int T = s.horizon();
+    double u[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < NU; ++r) u[r] = STORED ? s.uref(r, t) : (lp.u ? lp.u[r * T + t] : lp.cold[r]);
+    if (STORED) th = s.theta(t);
+    else if (lp.yaw) th = lp.yaw[t];
+    double Bm[3][4], C[3], omega;
+    linearize<MODEL>(v, th, u, a02, a12, Bm, C, omega);
+    th = th + omega * v.dt;   // used only when the yaw is rolled
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (v.eq_mode == MPCX_EQ_NONE) {
+            bt[r][0] = Bm[r][0]; bt[r][1] = Bm[r][1]; ct[r] = C[r];
+        } else if (v.eq_mode == MPCX_EQ_ACKERMANN) {
+            bt[r][0] = Bm[r][0] + Bm[r][2]; bt[r][1] = Bm[r][1] - Bm[r][3]; ct[r] = C[r];
+        } else if (v.eq_mode == MPCX_EQ_CRAB) {
+            bt[r][0] = Bm[r][0] + Bm[r][2]; bt[r][1] = Bm[r][1] + Bm[r][3]; ct[r] = C[r];
+        } else {
+            bt[r][0] = Bm[r][0]; bt[r][1] = Bm[r][2];
+            ct[r] = C[r] + (Bm[r][1] + Bm[r][3]) * v.steer_fixed;
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------
 // condensed QP assembly
@@ -309,9 +406,9 @@ struct MemStore {
 // Stage weights: none at t = 0 (`if t != 0`, mpc_diff_drive.py:181), Q * growth^t for
 // t = 1..T-1 (mpc_dsr.py:349), Qf at t = T.
 // ------------------------------------------------------------------------------------
-template <int MODEL, class S>
-__device__ __forceinline__ void assemble(S &s, const mpcx_variant &v, const double (&x0)[3],
-                                         const double *__restrict__ xref, bool roll_theta)
+template <int MODEL, bool STORED, class S>
+__device__ __forceinline__ void assemble(S &s, const mpcx_variant &v, const LinPoint &lp,
+                                         const double (&x0)[3], const double *__restrict__ xref)
 {
     const int T = s.horizon(), N = 2 * T, W = T + 1;
     double rw[2], rdw[2];
@@ -327,7 +424,7 @@ __device__ __forceinline__ void assemble(S &s, const mpcx_variant &v, const doub
     for (int i = 0; i < N; ++i) {
 #pragma unroll
         for (int j = 0; j <= i; ++j) s.Hacc(i, j) = 0.0;
-        s.g(i) = 0.0;
+        s.gacc(i) = 0.0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) s.G(r, i) = 0.0;
     }
@@ -342,32 +439,11 @@ __device__ __forceinline__ void assemble(S &s, const mpcx_variant &v, const doub
     }
     double p[3] = {x0[0], x0[1], x0[2]};
     double qg = 1.0;
-    double th = s.theta(0);
+    double th = lp.theta0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        double u[4], Bm[3][4], C[3], a02, a12, omega;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = (MODEL == MPCX_MODEL_DIFF_DRIVE && r >= 2) ? 0.0 : s.uref(r, t);
-        if (!roll_theta) th = s.theta(t);
-        linearize<MODEL>(v, th, u, a02, a12, Bm, C, omega);
-        th = th + omega * v.dt;   // only used when roll_theta
-        double bt[3][2], ct[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if (v.eq_mode == MPCX_EQ_NONE) {
-                bt[r][0] = Bm[r][0]; bt[r][1] = Bm[r][1]; ct[r] = C[r];
-            } else if (v.eq_mode == MPCX_EQ_ACKERMANN) {
-                bt[r][0] = Bm[r][0] + Bm[r][2]; bt[r][1] = Bm[r][1] - Bm[r][3]; ct[r] = C[r];
-            } else if (v.eq_mode == MPCX_EQ_CRAB) {
-                bt[r][0] = Bm[r][0] + Bm[r][2]; bt[r][1] = Bm[r][1] + Bm[r][3]; ct[r] = C[r];
-            } else {
-                bt[r][0] = Bm[r][0]; bt[r][1] = Bm[r][2];
-                ct[r] = C[r] + (Bm[r][1] + Bm[r][3]) * v.steer_fixed;
-            }
-        }
-        s.sa02(t) = a02; s.sa12(t) = a12;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { s.sb(t, 2 * r) = bt[r][0]; s.sb(t, 2 * r + 1) = bt[r][1]; s.sc(t, r) = ct[r]; }
+        double a02, a12, bt[3][2], ct[3];
+        stage_dynamics<MODEL, STORED>(s, v, lp, t, th, a02, a12, bt, ct);
         const double pn0 = p[0] + a02 * p[2] + ct[0];
         const double pn1 = p[1] + a12 * p[2] + ct[1];
         const double pn2 = p[2] + ct[2];
@@ -375,8 +451,8 @@ __device__ __forceinline__ void assemble(S &s, const mpcx_variant &v, const doub
 #pragma unroll
         for (int j = 0; j < 2 * t; ++j) {
             const double g2 = s.G(2, j);
-            s.G(0, j) += a02 * g2;
-            s.G(1, j) += a12 * g2;
+            s.G(0, j) = fma(a02, g2, s.G(0, j));
+            s.G(1, j) = fma(a12, g2, s.G(1, j));
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) { s.G(r, 2 * t) = bt[r][0]; s.G(r, 2 * t + 1) = bt[r][1]; }
@@ -397,16 +473,25 @@ __device__ __forceinline__ void assemble(S &s, const mpcx_variant &v, const doub
 #pragma unroll
             for (int i = 0; i < 2 * ts; ++i) {
                 const double gi = q2 * s.G(r, i);
-                s.g(i) += gi * e;
+                s.gacc(i) = fma(gi, e, s.gacc(i));
 #pragma unroll
-                for (int j = 0; j <= i; ++j) s.Hacc(i, j) += gi * s.G(r, j);
+                for (int j = 0; j <= i; ++j) s.Hacc(i, j) = fma(gi, s.G(r, j), s.Hacc(i, j));
             }
         }
     }
-    s.finishH();
+    s.finish_assembly();
 }
 
-// Cholesky K = L L' in place (right-looking), rinv = 1 / L_ii.
+// Reciprocal of a slack, already rounded to the precision it is stored in, so that the
+// barrier Hessian and every later use see exactly the same number.
+template <class S>
+__device__ __forceinline__ double slack_recip(double x)
+{
+    if (sizeof(typename S::aux_t) == sizeof(float)) return (double)(float)rcp_raw(x);
+    return rcp_nr(x);
+}
+
+// Cholesky K = L L' in place (right-looking); the diagonal is left holding 1 / L_ii.
 template <class S>
 __device__ __forceinline__ void chol_factor(S &s)
 {
@@ -414,7 +499,7 @@ __device__ __forceinline__ void chol_factor(S &s)
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const double r = rsqrt_nr(s.K(j, j));
-        s.rinv(j) = r;
+        s.K(j, j) = r;
 #pragma unroll
         for (int i = j + 1; i < N; ++i) s.K(i, j) *= r;
 #pragma unroll
@@ -436,7 +521,7 @@ __device__ __forceinline__ void chol_apply(S &s, V &&vec)
         double a = vec(i);
 #pragma unroll
         for (int k = 0; k < i; ++k) a = fma(-s.K(i, k), vec(k), a);
-        vec(i) = a * s.rinv(i);
+        vec(i) = a * s.K(i, i);
     }
 #pragma unroll
     for (int ii = 0; ii < N; ++ii) {
@@ -444,7 +529,31 @@ __device__ __forceinline__ void chol_apply(S &s, V &&vec)
         double a = vec(i);
 #pragma unroll
         for (int k = i + 1; k < N; ++k) a = fma(-s.K(k, i), vec(k), a);
-        vec(i) = a * s.rinv(i);
+        vec(i) = a * s.K(i, i);
+    }
+}
+
+// hw <- H w + g (symmetric packed H, one pass); optionally K <- H on the way.
+template <bool COPY_K, class S>
+__device__ __forceinline__ void hess_times_w(S &s)
+{
+    const int N = 2 * s.horizon();
+#pragma unroll
+    for (int i = 0; i < N; ++i) s.hw(i) = s.g(i);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const double wi = s.w(i);
+        double acc = s.hw(i);
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            const double h = s.H(i, j);
+            if (COPY_K) s.K(i, j) = h;
+            acc = fma(h, s.w(j), acc);
+            s.hw(j) = fma(h, wi, s.hw(j));
+        }
+        const double hd = s.H(i, i);
+        if (COPY_K) s.K(i, i) = hd;
+        s.hw(i) = fma(hd, wi, acc);
     }
 }
 
@@ -493,24 +602,8 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
     int my_iters = 0;
     status = MPCX_ST_FAILED;
     for (int it = 0;; ++it) {
-        // K <- H and hw <- H w + g, one pass over the Hessian
-#pragma unroll
-        for (int i = 0; i < N; ++i) s.hw(i) = s.g(i);
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const double wi = s.w(i);
-            double acc = s.hw(i);
-#pragma unroll
-            for (int j = 0; j < i; ++j) {
-                const double h = s.H(i, j);
-                s.K(i, j) = h;
-                acc = fma(h, s.w(j), acc);
-                s.hw(j) = fma(h, wi, s.hw(j));
-            }
-            const double hd = s.H(i, i);
-            s.K(i, i) = hd;
-            s.hw(i) = fma(hd, wi, acc);
-        }
+        hess_times_w<true>(s);   // K <- H and hw <- H w + g in one pass over the Hessian
+        MPCX_PHASE("SLACKS");
         // slacks, barrier Hessian terms, C'lambda (kept in dw), complementarity
         double musum = 0.0;
 #pragma unroll
@@ -520,15 +613,16 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
             if (hasbox(i)) {
                 const double wi = s.w(i);
                 const double su = dmax(hi_of(i) - wi, kSlackMin), sl = dmax(wi - lo_of(i), kSlackMin);
-                const double iu = rcp_nr(su), il = rcp_nr(sl);
+                const double iu = slack_recip<S>(su), il = slack_recip<S>(sl);
                 const double lu = s.lamU(i), ll = s.lamL(i);
-                s.isu(i) = iu; s.isl(i) = il;
+                s.isu(i) = (typename S::aux_t)(iu); s.isl(i) = (typename S::aux_t)(il);
                 s.K(i, i) += fma(lu, iu, ll * il);
                 s.dw(i) += lu - ll;
                 musum = fma(su, lu, fma(sl, ll, musum));
             } else {
-                s.isu(i) = 0.0; s.isl(i) = 0.0;
+                s.isu(i) = (typename S::aux_t)(0.0); s.isl(i) = (typename S::aux_t)(0.0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -536,9 +630,9 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
                 const double rr = fb.rr[i & 1];
                 const double dv = s.w(i + 2) - s.w(i);
                 const double ru = dmax(rr - dv, kSlackMin), rl = dmax(rr + dv, kSlackMin);
-                const double iu = rcp_nr(ru), il = rcp_nr(rl);
+                const double iu = slack_recip<S>(ru), il = slack_recip<S>(rl);
                 const double nu = s.nuU(i), nl = s.nuL(i);
-                s.iru(i) = iu; s.irl(i) = il;
+                s.iru(i) = (typename S::aux_t)(iu); s.irl(i) = (typename S::aux_t)(il);
                 const double d = fma(nu, iu, nl * il);
                 s.K(i, i) += d;
                 s.K(i + 2, i + 2) += d;
@@ -548,8 +642,9 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
                 s.dw(i) -= dn;
                 musum = fma(ru, nu, fma(rl, nl, musum));
             } else {
-                s.iru(i) = 0.0; s.irl(i) = 0.0;
+                s.iru(i) = (typename S::aux_t)(0.0); s.irl(i) = (typename S::aux_t)(0.0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const double mu = musum * inv_m;
         double rdmax = 0.0, scale = 1.0;
@@ -571,14 +666,17 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
         }
         if (__all(done)) break;
 
+        MPCX_PHASE("CHOL");
         chol_factor(s);
         auto chol_solve = [&](auto &&vec) { chol_apply(s, vec); };
 
+        MPCX_PHASE("PRED");
         // predictor: (H + C'DC) dwa = -(Hw + g)
 #pragma unroll
-        for (int i = 0; i < N; ++i) s.dwa(i) = -s.hw(i);
+        for (int i = 0; i < N; ++i) s.dwa(i) = -s.hw(i);   // in place: hw and dwa share storage
         chol_solve([&](int i) -> double & { return s.dwa(i); });
 
+        MPCX_PHASE("STATS");
         // x = (C dwa)_j / s_j ; primal ratio max x, dual ratio max (1 - x)
         double rp = 0.0, rdm = 1.0;
 #pragma unroll
@@ -589,6 +687,7 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
                 rp = dmax(rp, dmax(xu, xl));
                 rdm = dmax(rdm, dmax(1.0 - xu, 1.0 - xl));
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -598,6 +697,7 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
                 rp = dmax(rp, dmax(yu, yl));
                 rdm = dmax(rdm, dmax(1.0 - yu, 1.0 - yl));
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const double apa = rp > 1.0 ? rcp_nr(rp) : 1.0;
         const double ada = rcp_nr(rdm);
@@ -605,47 +705,51 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             if (hasbox(i)) {
-                const double wi = s.w(i), d = s.dwa(i);
+                const double wi = opaque(s.w(i)), d = opaque(s.dwa(i));
                 const double su = dmax(hi_of(i) - wi, kSlackMin), sl = dmax(wi - lo_of(i), kSlackMin);
                 const double xu = d * s.isu(i), xl = -d * s.isl(i);
                 muaff += (su * fma(-apa, xu, 1.0)) * (s.lamU(i) * fma(ada, xu - 1.0, 1.0));
                 muaff += (sl * fma(-apa, xl, 1.0)) * (s.lamL(i) * fma(ada, xl - 1.0, 1.0));
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             if (rt[i & 1]) {
                 const double rr = fb.rr[i & 1];
-                const double dv = s.w(i + 2) - s.w(i), d = s.dwa(i + 2) - s.dwa(i);
+                const double dv = opaque(s.w(i + 2) - s.w(i)), d = opaque(s.dwa(i + 2) - s.dwa(i));
                 const double ru = dmax(rr - dv, kSlackMin), rl = dmax(rr + dv, kSlackMin);
                 const double yu = d * s.iru(i), yl = -d * s.irl(i);
                 muaff += (ru * fma(-apa, yu, 1.0)) * (s.nuU(i) * fma(ada, yu - 1.0, 1.0));
                 muaff += (rl * fma(-apa, yl, 1.0)) * (s.nuL(i) * fma(ada, yl - 1.0, 1.0));
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         muaff *= inv_m;
         const double ratio = muaff * rcp_nr(dmax(mu, 1e-300));
         const double sm = ratio * ratio * ratio * mu;   // sigma * mu
 
-        // corrector: rhs = -(Hw+g) - C' q,  q_j = (sigma mu - ds_aff dl_aff)/s_j
-        //          = sigma mu / s_j + lambda_j x_j (x_j - 1)
+        MPCX_PHASE("CORR");
+        // corrector as a correction to the predictor: K (dw - dwa) = -C' q,
+        // q_j = (sigma mu - ds_aff dl_aff)/s_j = sigma mu / s_j + lambda_j x_j (x_j - 1)
 #pragma unroll
-        for (int i = 0; i < N; ++i) s.dw(i) = -s.hw(i);
+        for (int i = 0; i < N; ++i) s.dw(i) = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             if (hasbox(i)) {
-                const double d = s.dwa(i);
+                const double d = opaque(s.dwa(i));
                 const double iu = s.isu(i), il = s.isl(i);
                 const double xu = d * iu, xl = -d * il;
                 const double qu = fma(sm, iu, s.lamU(i) * xu * (xu - 1.0));
                 const double ql = fma(sm, il, s.lamL(i) * xl * (xl - 1.0));
                 s.dw(i) -= qu - ql;
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             if (rt[i & 1]) {
-                const double d = s.dwa(i + 2) - s.dwa(i);
+                const double d = opaque(s.dwa(i + 2) - s.dwa(i));
                 const double iu = s.iru(i), il = s.irl(i);
                 const double yu = d * iu, yl = -d * il;
                 const double qu = fma(sm, iu, s.nuU(i) * yu * (yu - 1.0));
@@ -654,15 +758,19 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
                 s.dw(i + 2) -= q;
                 s.dw(i) += q;
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         chol_solve([&](int i) -> double & { return s.dw(i); });
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.dw(i) += s.dwa(i);
 
+        MPCX_PHASE("FINAL");
         // dual steps (stored over the reciprocal slacks) and the two ratios
         double rp2 = 0.0, rd2 = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             if (hasbox(i)) {
-                const double da = s.dwa(i), d = s.dw(i);
+                const double da = opaque(s.dwa(i)), d = s.dw(i);
                 const double iu = s.isu(i), il = s.isl(i), lu = s.lamU(i), ll = s.lamL(i);
                 const double xu = da * iu, xl = -da * il;
                 const double qu = fma(sm, iu, lu * xu * (xu - 1.0));
@@ -671,13 +779,14 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
                 const double dlu = fma(lu, zu, qu - lu), dll = fma(ll, zl, ql - ll);
                 rp2 = dmax(rp2, dmax(zu, zl));
                 rd2 = dmax(rd2, dmax(-dlu * rcp_raw(lu), -dll * rcp_raw(ll)));
-                s.isu(i) = dlu; s.isl(i) = dll;
+                s.isu(i) = (typename S::aux_t)(dlu); s.isl(i) = (typename S::aux_t)(dll);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             if (rt[i & 1]) {
-                const double da = s.dwa(i + 2) - s.dwa(i), d = s.dw(i + 2) - s.dw(i);
+                const double da = opaque(s.dwa(i + 2) - s.dwa(i)), d = s.dw(i + 2) - s.dw(i);
                 const double iu = s.iru(i), il = s.irl(i), nu = s.nuU(i), nl = s.nuL(i);
                 const double yu = da * iu, yl = -da * il;
                 const double qu = fma(sm, iu, nu * yu * (yu - 1.0));
@@ -686,8 +795,9 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
                 const double dnu = fma(nu, zu, qu - nu), dnl = fma(nl, zl, ql - nl);
                 rp2 = dmax(rp2, dmax(zu, zl));
                 rd2 = dmax(rd2, dmax(-dnu * rcp_raw(nu), -dnl * rcp_raw(nl)));
-                s.iru(i) = dnu; s.irl(i) = dnl;
+                s.iru(i) = (typename S::aux_t)(dnu); s.irl(i) = (typename S::aux_t)(dnl);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const double eta = dmin(kEtaCap, dmax(0.99, 1.0 - mu));
         const double ap = rp2 > eta ? eta * rcp_nr(rp2) : 1.0;
@@ -719,12 +829,17 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
 // equalities and the equality-constrained QP is solved by three augmented-Lagrangian Newton
 // steps that share one Cholesky factor of K = H + rho * A_act' A_act.  Residuals are formed
 // with the true H, so the fixed point is the exact KKT point whatever the accuracy of the
-// factor.  The polished point replaces the iterate only if it is feasible for every
-// constraint, its multipliers are non-negative and it is stationary to rounding.
+// factor.  If the result violates a constraint that was left out, or gives a kept one a
+// negative multiplier, the set is corrected and the round repeated (at most kPolishRounds;
+// the wave leaves as soon as every lane is settled).  A lane takes the polished point only
+// if it is feasible for every constraint, its multipliers are non-negative and it is
+// stationary to rounding; otherwise it keeps the interior-point iterate.
 // Returns true when accepted.
 // ------------------------------------------------------------------------------------
+constexpr int kPolishRounds = 3;
+
 template <bool ALL, class S>
-__device__ __forceinline__ bool polish(S &s, const FreeBounds &fb)
+__device__ __forceinline__ bool polish(S &s, const FreeBounds &fb, bool skip)
 {
     const int T = s.horizon(), N = 2 * T, NR = N - 2;
     const bool bx[2] = {ALL || fb.box[0], ALL || fb.box[1]};
@@ -734,135 +849,154 @@ __device__ __forceinline__ bool polish(S &s, const FreeBounds &fb)
     auto hi_of = [&](int i) { return (i >> 1) == 0 ? fb.hi0[i & 1] : fb.b[i & 1]; };
     auto lo_of = [&](int i) { return (i >> 1) == 0 ? fb.lo0[i & 1] : -fb.b[i & 1]; };
 
-    // active flags (kept as 0/1 in the reciprocal-slack arrays), multipliers of the rest zeroed
     double hmax = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         hmax = dmax(hmax, s.H(i, i));
-        s.dwa(i) = s.w(i);   // backup of the interior-point iterate
-        double au = 0.0, al = 0.0;
-        if (hasbox(i)) {
-            const double wi = s.w(i);
-            au = s.lamU(i) > hi_of(i) - wi ? 1.0 : 0.0;
-            al = s.lamL(i) > wi - lo_of(i) ? 1.0 : 0.0;
-        }
-        s.isu(i) = au; s.isl(i) = al;
-        s.lamU(i) = au * s.lamU(i);
-        s.lamL(i) = al * s.lamL(i);
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        double au = 0.0, al = 0.0;
-        if (rt[i & 1]) {
-            const double rr = fb.rr[i & 1], dv = s.w(i + 2) - s.w(i);
-            au = s.nuU(i) > rr - dv ? 1.0 : 0.0;
-            al = s.nuL(i) > rr + dv ? 1.0 : 0.0;
-        }
-        s.iru(i) = au; s.irl(i) = al;
-        s.nuU(i) = au * s.nuU(i);
-        s.nuL(i) = al * s.nuL(i);
+        s.G(0, i) = s.w(i);   // what the lane falls back to: the interior-point iterate
     }
     const double rho = 1e5 * hmax;
+    bool accepted = false, settled = skip;
+    double scale = 1.0;
 
-    // K = H + rho A'A on the active rows, one factorisation
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-#pragma unroll
-        for (int j = 0; j < i; ++j) s.K(i, j) = s.H(i, j);
-        s.K(i, i) = fma(rho, s.isu(i) + s.isl(i), s.H(i, i));
-    }
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const double d = rho * (s.iru(i) + s.irl(i));
-        s.K(i, i) += d;
-        s.K(i + 2, i + 2) += d;
-        s.K(i + 2, i) -= d;
-    }
-    chol_factor(s);
-
-    double stat = 0.0, scale = 1.0;
 #pragma unroll 1
-    for (int pass = 0; pass < 4; ++pass) {
-        // hw = H w + g
-#pragma unroll
-        for (int i = 0; i < N; ++i) s.hw(i) = s.g(i);
+    for (int round = 0; round < kPolishRounds; ++round) {
+        // active flags, kept as 0/1 in the reciprocal-slack arrays.  First round: lambda_j > s_j.
+        // Later rounds: keep a constraint unless its multiplier went negative, add every
+        // violated one.
+        const double ntol = -1e-9 * scale;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const double wi = s.w(i);
-            double acc = s.hw(i);
-#pragma unroll
-            for (int j = 0; j < i; ++j) {
-                const double h = s.H(i, j);
-                acc = fma(h, s.w(j), acc);
-                s.hw(j) = fma(h, wi, s.hw(j));
+            double au = 0.0, al = 0.0;
+            if (hasbox(i)) {
+                const double wi = s.w(i), su = hi_of(i) - wi, sl = wi - lo_of(i);
+                if (round == 0) {
+                    au = s.lamU(i) > su ? 1.0 : 0.0;
+                    al = s.lamL(i) > sl ? 1.0 : 0.0;
+                } else {
+                    au = ((s.isu(i) != 0.0 && s.lamU(i) >= ntol) || su < -1e-12) ? 1.0 : 0.0;
+                    al = ((s.isl(i) != 0.0 && s.lamL(i) >= ntol) || sl < -1e-12) ? 1.0 : 0.0;
+                }
             }
-            s.hw(i) = fma(s.H(i, i), wi, acc);
-        }
-        // multiplier update with the constraint values at the current point (skipped on the
-        // first pass), then gradient of the Lagrangian (dw) and of the augmented one (hw)
-#pragma unroll
-        for (int i = 0; i < N; ++i) s.dw(i) = s.hw(i);
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const double wi = s.w(i);
-            const double cu = s.isu(i) * (wi - hi_of(i)), cl = s.isl(i) * (lo_of(i) - wi);
-            if (pass > 0) { s.lamU(i) = fma(rho, cu, s.lamU(i)); s.lamL(i) = fma(rho, cl, s.lamL(i)); }
-            const double t = s.lamU(i) - s.lamL(i);
-            s.dw(i) += t;
-            s.hw(i) += t + rho * (cu - cl);
+            s.isu(i) = (typename S::aux_t)(au); s.isl(i) = (typename S::aux_t)(al);
+            s.lamU(i) = au * dmax(s.lamU(i), 0.0);
+            s.lamL(i) = al * dmax(s.lamL(i), 0.0);
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const double rr = fb.rr[i & 1], dv = s.w(i + 2) - s.w(i);
-            const double cu = s.iru(i) * (dv - rr), cl = s.irl(i) * (-dv - rr);
-            if (pass > 0) { s.nuU(i) = fma(rho, cu, s.nuU(i)); s.nuL(i) = fma(rho, cl, s.nuL(i)); }
-            const double t = s.nuU(i) - s.nuL(i);
-            s.dw(i + 2) += t; s.dw(i) -= t;
-            const double ta = t + rho * (cu - cl);
-            s.hw(i + 2) += ta; s.hw(i) -= ta;
+            double au = 0.0, al = 0.0;
+            if (rt[i & 1]) {
+                const double rr = fb.rr[i & 1], dv = s.w(i + 2) - s.w(i);
+                if (round == 0) {
+                    au = s.nuU(i) > rr - dv ? 1.0 : 0.0;
+                    al = s.nuL(i) > rr + dv ? 1.0 : 0.0;
+                } else {
+                    au = ((s.iru(i) != 0.0 && s.nuU(i) >= ntol) || rr - dv < -1e-12) ? 1.0 : 0.0;
+                    al = ((s.irl(i) != 0.0 && s.nuL(i) >= ntol) || rr + dv < -1e-12) ? 1.0 : 0.0;
+                }
+            }
+            s.iru(i) = (typename S::aux_t)(au); s.irl(i) = (typename S::aux_t)(al);
+            s.nuU(i) = au * dmax(s.nuU(i), 0.0);
+            s.nuL(i) = al * dmax(s.nuL(i), 0.0);
         }
-        stat = 0.0; scale = 1.0;
+
+        // K = H + rho A'A on the active rows, one factorisation per round
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            stat = dmax(stat, fabs(s.dw(i)));
-            scale = dmax(scale, dmax(fabs(s.g(i)), fabs(s.dw(i) - s.hw(i))));
+#pragma unroll
+            for (int j = 0; j < i; ++j) s.K(i, j) = s.H(i, j);
+            s.K(i, i) = fma(rho, s.isu(i) + s.isl(i), s.H(i, i));
         }
-        if (pass == 3) break;
-        // Newton step on the augmented Lagrangian
 #pragma unroll
-        for (int i = 0; i < N; ++i) s.hw(i) = -s.hw(i);
-        chol_apply(s, [&](int i) -> double & { return s.hw(i); });
-#pragma unroll
-        for (int i = 0; i < N; ++i) s.w(i) += s.hw(i);
-    }
-    // acceptance: stationary, every constraint satisfied, multipliers non-negative, close by
-    double viol = 0.0, neg = 0.0, far = 0.0, cact = 0.0;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const double wi = s.w(i);
-        far = dmax(far, fabs(wi - s.dwa(i)));
-        if (hasbox(i)) {
-            viol = dmax(viol, dmax(wi - hi_of(i), lo_of(i) - wi));
-            cact = dmax(cact, dmax(s.isu(i) * fabs(wi - hi_of(i)), s.isl(i) * fabs(lo_of(i) - wi)));
+        for (int i = 0; i < NR; ++i) {
+            const double d = rho * (s.iru(i) + s.irl(i));
+            s.K(i, i) += d;
+            s.K(i + 2, i + 2) += d;
+            s.K(i + 2, i) -= d;
         }
-        neg = dmax(neg, dmax(-s.lamU(i), -s.lamL(i)));
-    }
+        chol_factor(s);
+
+        double stat = 0.0;
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+            hess_times_w<false>(s);
+            // multiplier update with the constraint values at the current point (not on the
+            // first pass), then gradient of the Lagrangian (dw) and of the augmented one (hw)
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        if (rt[i & 1]) {
-            const double rr = fb.rr[i & 1], dv = s.w(i + 2) - s.w(i);
-            viol = dmax(viol, dmax(dv - rr, -dv - rr));
-            cact = dmax(cact, dmax(s.iru(i) * fabs(dv - rr), s.irl(i) * fabs(-dv - rr)));
+            for (int i = 0; i < N; ++i) s.dw(i) = s.hw(i);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                if (hasbox(i)) {
+                    const double wi = s.w(i);
+                    const double cu = s.isu(i) * (wi - hi_of(i)), cl = s.isl(i) * (lo_of(i) - wi);
+                    if (pass > 0) { s.lamU(i) = fma(rho, cu, s.lamU(i)); s.lamL(i) = fma(rho, cl, s.lamL(i)); }
+                    const double t = s.lamU(i) - s.lamL(i);
+                    s.dw(i) += t;
+                    s.hw(i) += t + rho * (cu - cl);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                if (rt[i & 1]) {
+                    const double rr = fb.rr[i & 1], dv = s.w(i + 2) - s.w(i);
+                    const double cu = s.iru(i) * (dv - rr), cl = s.irl(i) * (-dv - rr);
+                    if (pass > 0) { s.nuU(i) = fma(rho, cu, s.nuU(i)); s.nuL(i) = fma(rho, cl, s.nuL(i)); }
+                    const double t = s.nuU(i) - s.nuL(i);
+                    s.dw(i + 2) += t; s.dw(i) -= t;
+                    const double ta = t + rho * (cu - cl);
+                    s.hw(i + 2) += ta; s.hw(i) -= ta;
+                }
+            }
+            stat = 0.0; scale = 1.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                stat = dmax(stat, fabs(s.dw(i)));
+                scale = dmax(scale, dmax(fabs(s.g(i)), fabs(s.dw(i) - s.hw(i))));
+            }
+            scale += 1.0;
+            if (pass == 3) break;
+            // Newton step on the augmented Lagrangian
+#pragma unroll
+            for (int i = 0; i < N; ++i) s.hw(i) = -s.hw(i);
+            chol_apply(s, [&](int i) -> double & { return s.hw(i); });
+            if (!settled) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) s.w(i) += s.hw(i);
+            }
         }
-        neg = dmax(neg, dmax(-s.nuU(i), -s.nuL(i)));
-    }
-    scale += 1.0;
-    const bool ok = stat <= 1e-10 * scale && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale && far <= 1e-3;
-    if (!ok) {
+        // acceptance: stationary, every constraint satisfied, multipliers non-negative, close by
+        double viol = 0.0, neg = 0.0, far = 0.0, cact = 0.0;
 #pragma unroll
-        for (int i = 0; i < N; ++i) s.w(i) = s.dwa(i);
+        for (int i = 0; i < N; ++i) {
+            const double wi = s.w(i);
+            far = dmax(far, fabs(wi - s.G(0, i)));
+            if (hasbox(i)) {
+                viol = dmax(viol, dmax(wi - hi_of(i), lo_of(i) - wi));
+                cact = dmax(cact, dmax(s.isu(i) * fabs(wi - hi_of(i)), s.isl(i) * fabs(lo_of(i) - wi)));
+                neg = dmax(neg, dmax(-s.lamU(i), -s.lamL(i)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            if (rt[i & 1]) {
+                const double rr = fb.rr[i & 1], dv = s.w(i + 2) - s.w(i);
+                viol = dmax(viol, dmax(dv - rr, -dv - rr));
+                cact = dmax(cact, dmax(s.iru(i) * fabs(dv - rr), s.irl(i) * fabs(-dv - rr)));
+                neg = dmax(neg, dmax(-s.nuU(i), -s.nuL(i)));
+            }
+        }
+        if (!settled) {
+            const bool sane = stat <= 1e-10 * scale && far <= 1e-3;   // NaN fails both
+            if (sane && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) { accepted = true; settled = true; }
+            else if (!sane) settled = true;   // not an active-set problem: keep the iterate
+        }
+        if (__all(settled)) break;
     }
-    return ok;
+    if (!accepted) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) s.w(i) = s.G(0, i);
+    }
+    return accepted;
 }
 
 }  // namespace mpcx

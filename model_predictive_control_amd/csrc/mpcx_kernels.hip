@@ -26,7 +26,9 @@ struct SolveArgs {
     int32_t max_iter;
 };
 
-template <int MODEL, bool ALL, class S>
+// STORED: the linearisation point lives in the store (chained mpc_sim solves, and the
+// memory-resident path); otherwise it is read from the caller's buffers when needed.
+template <int MODEL, bool ALL, bool STORED, class S>
 __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b, bool live)
 {
     const mpcx_variant &v = a.v;
@@ -41,44 +43,36 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
     const double *uin = a.uin ? a.uin + b * NU * T : nullptr;
     const bool warm = a.linear_mode || (uin && (!a.has_prev || a.has_prev[b]));
     const int chain = a.linear_mode ? 1 : (v.chain > 1 ? (v.chain < T ? v.chain : T) : 1);
-    bool roll_theta = false;
-
+    LinPoint lp;
+    lp.u = warm ? uin : nullptr;
+    lp.cold = v.cold_start;
+    lp.yaw = nullptr;
+    lp.theta0 = x0[2];
     if (a.linear_mode) {
         const double *xb = a.xbar + b * 3 * W;
 #pragma unroll
         for (int i = 0; i < 3 * W; ++i) finite = finite && finite_d(xb[i]);
-#pragma unroll
-        for (int t = 0; t < T; ++t) s.theta(t) = xb[2 * W + t];
+        lp.yaw = xb + 2 * W;
     }
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double val = 0.0;
-            if (r < NU) val = warm ? uin[r * T + t] : v.cold_start[r];
-            finite = finite && finite_d(val);
-            s.uref(r, t) = val;
-        }
-    if (!a.linear_mode) {
-        if (chain <= 1) {
-            s.theta(0) = x0[2];
-            roll_theta = true;   // yaw of predict_motion is produced while linearising
-        } else {
-            // mpc_sim.py:294: xbar comes from the incoming controls and stays fixed while the
-            // chained solves refill uref column by column (:295-308)
-            double th = x0[2];
+        for (int r = 0; r < NU; ++r) finite = finite && finite_d(lp.u ? lp.u[r * T + t] : lp.cold[r]);
+
+    if (STORED) {
+        // xbar[2][t] of the incoming controls (predict_motion), kept fixed over chained solves
+        // (mpc_sim.py:294); uref starts as the incoming controls, or, when chaining, as column 0
+        // of them with the rest zero (mpc_sim.py:292,295-299)
+        double th = x0[2];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                s.theta(t) = th;
-                double u[4];
+        for (int t = 0; t < T; ++t) {
+            double u[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) u[r] = s.uref(r, t);
-                th = th + yaw_rate<MODEL>(v, u) * v.dt;
-            }
+            for (int r = 0; r < NU; ++r) u[r] = lp.u ? lp.u[r * T + t] : lp.cold[r];
+            s.theta(t) = lp.yaw ? lp.yaw[t] : th;
+            th = th + yaw_rate<MODEL>(v, u) * v.dt;
 #pragma unroll
-            for (int t = 1; t < T; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s.uref(r, t) = 0.0;
+            for (int r = 0; r < 4; ++r) s.uref(r, t) = (chain > 1 && t > 0) ? 0.0 : u[r];
         }
     }
 
@@ -87,6 +81,7 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
     if (!finite) {
         status = MPCX_ST_NONFINITE;
         x0[0] = x0[1] = x0[2] = 0.0;
+        lp.theta0 = 0.0;
     }
     const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
     auto controls = [&](int t, double (&u)[4]) {
@@ -96,10 +91,10 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
         else { u[0] = w0; u[1] = w1; u[2] = w0; u[3] = sg * w1; }
     };
 
-    for (int pass = 0; pass < chain; ++pass) {
-        if (pass > 0) {   // column `pass` of uref <- previous solution (mpc_sim.py:296-299 after :302)
+    for (int pass = 0; pass < (STORED ? chain : 1); ++pass) {
+        if (STORED && pass > 0) {   // column `pass` of uref <- previous answer (mpc_sim.py:296-299 after :302)
 #pragma unroll
-            for (int t = 1; t < T; ++t) {   // static indices, runtime predicate: keeps the arrays in registers
+            for (int t = 1; t < T; ++t) {   // static indices under a runtime predicate: arrays stay in registers
                 if (t == pass) {
                     double u[4];
                     controls(t, u);
@@ -108,10 +103,10 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
                 }
             }
         }
-        assemble<MODEL>(s, v, x0, xr, roll_theta);
-        double u0[4];
+        assemble<MODEL, STORED>(s, v, lp, x0, xr);
+        double u0[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u0[r] = s.uref(r, 0);
+        for (int r = 0; r < NU; ++r) u0[r] = STORED ? s.uref(r, 0) : (lp.u ? lp.u[r * T] : lp.cold[r]);
         FreeBounds fb;
         free_bounds(v, u0, fb);
         if (!fb.feasible && !skip) { skip = true; status = MPCX_ST_INFEASIBLE; }
@@ -122,12 +117,13 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
             status = st;
             if (st == MPCX_ST_FAILED) skip = true;
         }
-        const bool polished = polish<ALL>(s, fb);
+        const bool polished = polish<ALL>(s, fb, skip);
         if (!skip && polished) status = MPCX_ST_OK;
     }
 
-    // controls, predicted states, objective (cost expression of mpc_diff_drive.py:178-193
-    // plus the difference term of mpc.py:152-153, evaluated at the returned point)
+    // controls, predicted states (the linearised dynamics re-evaluated stage by stage),
+    // objective = the cost expression of mpc_diff_drive.py:178-193 plus the difference term
+    // of mpc.py:152-153 at the returned point
     const bool bad = status == MPCX_ST_NONFINITE || status == MPCX_ST_INFEASIBLE;
     const double nan = __builtin_nan("");
     double J = 0.0, qg = 1.0;
@@ -138,6 +134,7 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
 #pragma unroll
         for (int r = 0; r < 3; ++r) xo[r * W] = bad ? nan : x[r];
     }
+    double th = lp.theta0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         double u[4];
@@ -150,9 +147,11 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
             up[r] = u[r];
             if (live) uo[r * T + t] = bad ? nan : u[r];
         }
-        const double n0 = x[0] + s.sa02(t) * x[2] + s.sb(t, 0) * w0 + s.sb(t, 1) * w1 + s.sc(t, 0);
-        const double n1 = x[1] + s.sa12(t) * x[2] + s.sb(t, 2) * w0 + s.sb(t, 3) * w1 + s.sc(t, 1);
-        const double n2 = x[2] + s.sb(t, 4) * w0 + s.sb(t, 5) * w1 + s.sc(t, 2);
+        double a02, a12, bt[3][2], ct[3];
+        stage_dynamics<MODEL, STORED>(s, v, lp, t, th, a02, a12, bt, ct);
+        const double n0 = x[0] + a02 * x[2] + bt[0][0] * w0 + bt[0][1] * w1 + ct[0];
+        const double n1 = x[1] + a12 * x[2] + bt[1][0] * w0 + bt[1][1] * w1 + ct[1];
+        const double n2 = x[2] + bt[2][0] * w0 + bt[2][1] * w1 + ct[2];
         x[0] = n0; x[1] = n1; x[2] = n2;
         const int ts = t + 1;
         if (ts < T) qg *= v.q_growth;
@@ -171,16 +170,16 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
     }
 }
 
-template <int MODEL, int T, bool ALL>
+template <int MODEL, int T, bool CHAIN>
 __global__ __launch_bounds__(kWave) void k_solve_reg(SolveArgs a)
 {
-    __shared__ double Hs[RegStore<T>::NT * kWave];
+    __shared__ double Hs[RegStore<T>::kLdsDoubles * kWave];
     RegStore<T> s;
-    s.Hs = Hs + threadIdx.x;
+    s.Hs = (typename RegStore<T>::lds_double *)Hs + threadIdx.x;
     int64_t b = (int64_t)blockIdx.x * kWave + threadIdx.x;
     const bool live = b < a.B;
     if (!live) b = a.B - 1;   // idle lanes redo the last instance so wave votes stay uniform
-    run_instance<MODEL, ALL>(s, a, b, live);
+    run_instance<MODEL, true, CHAIN>(s, a, b, live);
 }
 
 template <int MODEL>
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(kWave) void k_solve_mem(SolveArgs a, double *ws, in
     int64_t b = slot;
     const bool live = b < a.B;
     if (!live) b = a.B - 1;
-    run_instance<MODEL, false>(s, a, b, live);
+    run_instance<MODEL, false, true>(s, a, b, live);
 }
 
 // ------------------------------------------------------------------------------------
@@ -381,7 +380,8 @@ static bool all_present(const mpcx_variant *v)
            (fin(v->dumax[0]) || fin(v->dumax[2])) && (fin(v->dumax[1]) || fin(v->dumax[3]));
 }
 
-static bool uses_registers(const mpcx_variant *v) { return v->T == 5; }
+// the register-resident kernels are built for T = 5 with every bound present
+static bool uses_registers(const mpcx_variant *v) { return v->T == 5 && all_present(v); }
 
 // grow-only per-device workspace for the memory-resident path
 static std::mutex g_ws_mutex;
@@ -402,12 +402,12 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
     if (a.B == 0) return 0;
     if (uses_registers(v)) {
         const dim3 grid((unsigned)((a.B + kWave - 1) / kWave)), block(kWave);
-        const bool all = all_present(v);
+        const bool chained = !a.linear_mode && v->chain > 1;
         if (v->model == MPCX_MODEL_DIFF_DRIVE) {
-            if (all) hipLaunchKernelGGL((k_solve_reg<0, 5, true>), grid, block, 0, st, a);
+            if (chained) hipLaunchKernelGGL((k_solve_reg<0, 5, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((k_solve_reg<0, 5, false>), grid, block, 0, st, a);
         } else {
-            if (all) hipLaunchKernelGGL((k_solve_reg<1, 5, true>), grid, block, 0, st, a);
+            if (chained) hipLaunchKernelGGL((k_solve_reg<1, 5, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((k_solve_reg<1, 5, false>), grid, block, 0, st, a);
         }
         hipError_t e = hipGetLastError();

@@ -450,83 +450,103 @@ static void lu_solve(const double *M, const int *piv, int N, double *b)
 
 /* Active-set polish of an interior-point answer: equality-constrained QP on the constraints
  * the iterate marks active (lam_j > s_j), regularised KKT system plus refinement against the
- * unregularised one.  The iterate is only ~sqrt(mu) accurate on weakly active constraints;
- * the polished point is exact to rounding.  Accepted only when feasible, dual feasible,
- * stationary to rounding and close to the iterate; otherwise the iterate is kept. */
+ * unregularised one; if the result violates a constraint left out, or gives a kept one a
+ * negative multiplier, the set is fixed and the solve repeated (a few rounds of a primal-dual
+ * active-set method from a very good guess).  The iterate is only ~sqrt(mu) accurate on
+ * weakly active constraints; the polished point is exact to rounding.  Accepted only when
+ * feasible, dual feasible, stationary to rounding and close to the iterate; otherwise the
+ * iterate is kept. */
 static void polish(const qp_t *q, const int *ip, const int *im, int m, double *w, const double *s,
                    double *lam)
 {
-    int n = q->n, k = 0;
+    int n = q->n;
+    int Nmax = n + m;
+    int *active = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
     int *act = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1));
-    for (int j = 0; j < m; ++j) if (lam[j] > s[j]) act[k++] = j;
-    int N = n + k;
-    double *M = (double *)calloc((size_t)N * N, sizeof(double));
-    double *rhs = (double *)malloc(sizeof(double) * N), *sol = (double *)calloc(N, sizeof(double));
-    double *res = (double *)malloc(sizeof(double) * N);
-    int *piv = (int *)malloc(sizeof(int) * N);
+    double *M = (double *)malloc(sizeof(double) * (size_t)Nmax * Nmax);
+    double *rhs = (double *)malloc(sizeof(double) * Nmax), *sol = (double *)malloc(sizeof(double) * Nmax);
+    double *res = (double *)malloc(sizeof(double) * Nmax), *lamp = (double *)malloc(sizeof(double) * (m > 0 ? m : 1));
+    int *piv = (int *)malloc(sizeof(int) * Nmax);
     const double delta = 1e-13;
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) M[i * N + j] = q->H[i * n + j];
-    for (int a = 0; a < k; ++a) {
-        int j = act[a];
-        if (ip[j] >= 0) { M[(n + a) * N + ip[j]] = 1.0; M[ip[j] * N + n + a] = 1.0; }
-        if (im[j] >= 0) { M[(n + a) * N + im[j]] = -1.0; M[im[j] * N + n + a] = -1.0; }
-        M[(n + a) * N + n + a] = -delta;
+    double scale = 1.0;
+    for (int i = 0; i < n; ++i) {
+        double a = 0.0;
+        for (int j = 0; j < n; ++j) a += q->H[i * n + j] * w[j];
+        if (fabs(a) + 1.0 > scale) scale = fabs(a) + 1.0;
+        if (fabs(q->g[i]) + 1.0 > scale) scale = fabs(q->g[i]) + 1.0;
     }
-    for (int i = 0; i < n; ++i) rhs[i] = -q->g[i];
-    for (int a = 0; a < k; ++a) rhs[n + a] = q->d[act[a]];
-    int ok = lu_factor(M, piv, N) == 0;
-    for (int pass = 0; ok && pass < 4; ++pass) {
-        /* res = rhs - KKT0 * sol (delta = 0) */
-        for (int i = 0; i < n; ++i) {
-            double a = rhs[i];
-            for (int j = 0; j < n; ++j) a -= q->H[i * n + j] * sol[j];
-            res[i] = a;
-        }
+    for (int j = 0; j < m; ++j) active[j] = lam[j] > s[j];
+    for (int round = 0; round < 6; ++round) {
+        int k = 0;
+        for (int j = 0; j < m; ++j) if (active[j]) act[k++] = j;
+        int N = n + k;
+        memset(M, 0, sizeof(double) * (size_t)N * N);
+        memset(sol, 0, sizeof(double) * N);
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) M[i * N + j] = q->H[i * n + j];
         for (int a = 0; a < k; ++a) {
             int j = act[a];
-            double nu = sol[n + a];
-            if (ip[j] >= 0) res[ip[j]] -= nu;
-            if (im[j] >= 0) res[im[j]] += nu;
-            res[n + a] = rhs[n + a] - crow(ip, im, j, sol);
+            if (ip[j] >= 0) { M[(n + a) * N + ip[j]] = 1.0; M[ip[j] * N + n + a] = 1.0; }
+            if (im[j] >= 0) { M[(n + a) * N + im[j]] = -1.0; M[im[j] * N + n + a] = -1.0; }
+            M[(n + a) * N + n + a] = -delta;
         }
-        lu_solve(M, piv, N, res);
-        for (int i = 0; i < N; ++i) sol[i] += res[i];
-    }
-    for (int i = 0; ok && i < N; ++i) if (!isfinite(sol[i])) ok = 0;
-    if (ok) {
-        double scale = 1.0, stat = 0.0, numin = 0.0, close = 0.0;
-        double *hv = res; /* reuse */
+        for (int i = 0; i < n; ++i) rhs[i] = -q->g[i];
+        for (int a = 0; a < k; ++a) rhs[n + a] = q->d[act[a]];
+        if (lu_factor(M, piv, N) != 0) break;
+        for (int pass = 0; pass < 4; ++pass) {
+            /* res = rhs - KKT0 * sol (delta = 0) */
+            for (int i = 0; i < n; ++i) {
+                double a = rhs[i];
+                for (int j = 0; j < n; ++j) a -= q->H[i * n + j] * sol[j];
+                res[i] = a;
+            }
+            for (int a = 0; a < k; ++a) {
+                int j = act[a];
+                double nu = sol[n + a];
+                if (ip[j] >= 0) res[ip[j]] -= nu;
+                if (im[j] >= 0) res[im[j]] += nu;
+                res[n + a] = rhs[n + a] - crow(ip, im, j, sol);
+            }
+            lu_solve(M, piv, N, res);
+            for (int i = 0; i < N; ++i) sol[i] += res[i];
+        }
+        int finite = 1;
+        for (int i = 0; i < N; ++i) if (!isfinite(sol[i])) finite = 0;
+        if (!finite) break;
+        double stat = 0.0, numin = 0.0, close = 0.0, viol = -1.0;
+        double *hv = res;
         for (int i = 0; i < n; ++i) {
             double a = 0.0;
             for (int j = 0; j < n; ++j) a += q->H[i * n + j] * sol[j];
-            if (fabs(a) > scale - 1.0) scale = 1.0 + fabs(a);
-            if (fabs(q->g[i]) > scale - 1.0) scale = 1.0 + fabs(q->g[i]);
             hv[i] = a + q->g[i];
             if (fabs(sol[i] - w[i]) > close) close = fabs(sol[i] - w[i]);
         }
+        for (int j = 0; j < m; ++j) lamp[j] = 0.0;
         for (int a = 0; a < k; ++a) {
             int j = act[a];
             double nu = sol[n + a];
+            lamp[j] = nu;
             if (nu < numin) numin = nu;
             if (ip[j] >= 0) hv[ip[j]] += nu;
             if (im[j] >= 0) hv[im[j]] -= nu;
         }
         for (int i = 0; i < n; ++i) if (fabs(hv[i]) > stat) stat = fabs(hv[i]);
-        double viol = -1.0;
         for (int j = 0; j < m; ++j) { double g = crow(ip, im, j, sol) - q->d[j]; if (g > viol) viol = g; }
-        if (viol <= 1e-12 && numin >= -1e-9 * scale && stat <= 1e-11 * scale && close <= 1e-3) {
+        int ok_stat = stat <= 1e-11 * scale, ok_close = close <= 1e-3;
+        if (viol <= 1e-12 && numin >= -1e-9 * scale && ok_stat && ok_close) {
             for (int i = 0; i < n; ++i) w[i] = sol[i];
-            for (int j = 0; j < m; ++j) lam[j] = 0.0;
-            for (int a = 0; a < k; ++a) lam[act[a]] = sol[n + a] > 0.0 ? sol[n + a] : 0.0;
+            for (int j = 0; j < m; ++j) lam[j] = lamp[j] > 0.0 ? lamp[j] : 0.0;
+            break;
+        }
+        if (!ok_stat || !ok_close) break;
+        for (int j = 0; j < m; ++j) {
+            double g = crow(ip, im, j, sol) - q->d[j];
+            active[j] = (active[j] && lamp[j] >= -1e-9 * scale) || g > 1e-12;
         }
     }
-    free(act); free(M); free(rhs); free(sol); free(res); free(piv);
+    free(active); free(act); free(M); free(rhs); free(sol); free(res); free(lamp); free(piv);
 }
 
-
-/* Mehrotra predictor-corrector; returns iterations, *conv = 1 if the 1e-11 test passed,
- * 0 if only the loose (1e-7) one did, -1 if neither. */
 static int g_polish = 1; /* orc_set_polish(): tests keep it on, the timed CPU baseline turns it off */
 
 static int ipm(const qp_t *q, const int *ip, const int *im, int m, double *w, double *lam_out,
