@@ -826,8 +826,8 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
 // ------------------------------------------------------------------------------------
 // Active-set polish.  The interior-point iterate is only ~sqrt(mu) accurate on weakly
 // active constraints; here the constraints it marks active (lambda_j > s_j) are imposed as
-// equalities and the equality-constrained QP is solved by three augmented-Lagrangian Newton
-// steps that share one Cholesky factor of K = H + rho * A_act' A_act.  Residuals are formed
+// equalities and the equality-constrained QP is solved by two augmented-Lagrangian Newton
+// steps (each shrinks the constraint residual by ~H/rho = 1e-5) that share one Cholesky factor of K = H + rho * A_act' A_act.  Residuals are formed
 // with the true H, so the fixed point is the exact KKT point whatever the accuracy of the
 // factor.  If the result violates a constraint that was left out, or gives a kept one a
 // negative multiplier, the set is corrected and the round repeated (at most kPolishRounds;
@@ -918,7 +918,7 @@ __device__ __forceinline__ bool polish(S &s, const FreeBounds &fb, bool skip)
 
         double stat = 0.0;
 #pragma unroll 1
-        for (int pass = 0; pass < 4; ++pass) {
+        for (int pass = 0; pass < 3; ++pass) {
             hess_times_w<false>(s);
             // multiplier update with the constraint values at the current point (not on the
             // first pass), then gradient of the Lagrangian (dw) and of the augmented one (hw)
@@ -954,7 +954,7 @@ __device__ __forceinline__ bool polish(S &s, const FreeBounds &fb, bool skip)
                 scale = dmax(scale, dmax(fabs(s.g(i)), fabs(s.dw(i) - s.hw(i))));
             }
             scale += 1.0;
-            if (pass == 3) break;
+            if (pass == 2) break;
             // Newton step on the augmented Lagrangian
 #pragma unroll
             for (int i = 0; i < N; ++i) s.hw(i) = -s.hw(i);

@@ -143,8 +143,9 @@ class ModelPredictiveControl:
         if not self.isReferenceRetrived_:
             return None
         last = -1
+        px, py = float(np.ravel(x_current[0])[0]), float(np.ravel(x_current[1])[0])
         for i in range(len(self.pts_x_)):
-            if math.sqrt((x_current[0] - self.pts_x_[i]) ** 2 + (x_current[1] - self.pts_y_[i]) ** 2) < self.trim_dist_:
+            if math.sqrt((px - self.pts_x_[i]) ** 2 + (py - self.pts_y_[i]) ** 2) < self.trim_dist_:
                 last = i
         if last >= 0:
             del self.pts_x_[:last + 1]
