@@ -4,11 +4,13 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
 #include "mpcx.h"
 #include "mpcx_device.h"
+#include "mpcx_pair.h"
 
 namespace mpcx {
 
@@ -180,6 +182,129 @@ __global__ __launch_bounds__(kWave) void k_solve_reg(SolveArgs a)
     const bool live = b < a.B;
     if (!live) b = a.B - 1;   // idle lanes redo the last instance so wave votes stay uniform
     run_instance<MODEL, true, CHAIN>(s, a, b, live);
+}
+
+// Two lanes per instance (T = 5, every bound present, single QP per call).
+template <int MODEL>
+__global__ __launch_bounds__(kWave, 2) void k_solve_pair(SolveArgs a)
+{
+    __shared__ double Hs[pair::kLdsPerLane * kWave];
+    constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
+    constexpr int T = pair::TT, W = T + 1;
+    const mpcx_variant &v = a.v;
+    pair::State s;
+    s.lds = (pair::lds_double *)Hs + threadIdx.x;
+    const int64_t lane = (int64_t)blockIdx.x * kWave + threadIdx.x;
+    s.odd = (lane & 1) != 0;
+    int64_t b = lane >> 1;
+    const bool live = b < a.B;
+    if (!live) b = a.B - 1;   // idle pairs redo the last instance so wave votes stay uniform
+
+    const double *__restrict__ xr = a.xref + b * 3 * W;
+    double x0[3] = {a.x0[b * 3], a.x0[b * 3 + 1], a.x0[b * 3 + 2]};
+    bool finite = finite_d(x0[0]) && finite_d(x0[1]) && finite_d(x0[2]);
+#pragma unroll
+    for (int i = 0; i < 3 * W; ++i) finite = finite && finite_d(xr[i]);
+    const double *uin = a.uin ? a.uin + b * NU * T : nullptr;
+    const bool warm = a.linear_mode || (uin && (!a.has_prev || a.has_prev[b]));
+    LinPoint lp;
+    lp.u = warm ? uin : nullptr;
+    lp.cold = v.cold_start;
+    lp.yaw = nullptr;
+    lp.theta0 = x0[2];
+    if (a.linear_mode) {
+        const double *xb = a.xbar + b * 3 * W;
+#pragma unroll
+        for (int i = 0; i < 3 * W; ++i) finite = finite && finite_d(xb[i]);
+        lp.yaw = xb + 2 * W;
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < NU; ++r) finite = finite && finite_d(lp.u ? lp.u[r * T + t] : lp.cold[r]);
+
+    int status = MPCX_ST_OK, iters = 0;
+    bool skip = !finite;
+    if (!finite) {
+        status = MPCX_ST_NONFINITE;
+        x0[0] = x0[1] = x0[2] = 0.0;
+        lp.theta0 = 0.0;
+    }
+    pair::assemble<MODEL>(s, v, lp, x0, xr);
+    {
+        double u0[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < NU; ++r) u0[r] = lp.u ? lp.u[r * T] : lp.cold[r];
+        FreeBounds fb;
+        free_bounds(v, u0, fb);
+        if (!fb.feasible && !skip) { skip = true; status = MPCX_ST_INFEASIBLE; }
+        s.b = s.odd ? fb.b[1] : fb.b[0];
+        s.rr = s.odd ? fb.rr[1] : fb.rr[0];
+        s.lo0 = s.odd ? fb.lo0[1] : fb.lo0[0];
+        s.hi0 = s.odd ? fb.hi0[1] : fb.hi0[0];
+    }
+    {
+        int st = MPCX_ST_OK, it = 0;
+        pair::ipm(s, a.max_iter, skip, st, it);
+        if (!skip) {
+            iters = it;
+            status = st;
+            if (st == MPCX_ST_FAILED) skip = true;
+        }
+        const bool polished = pair::polish(s, skip);
+        if (!skip && polished) status = MPCX_ST_OK;
+    }
+
+    // epilogue (both lanes evaluate it; the even lane stores the controls, the odd lane the states)
+    const bool bad = status == MPCX_ST_NONFINITE || status == MPCX_ST_INFEASIBLE;
+    const double nan = __builtin_nan("");
+    const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
+    double J = 0.0, qg = 1.0;
+    double x[3] = {x0[0], x0[1], x0[2]};
+    double up[4] = {0, 0, 0, 0};
+    double *uo = a.u_out + b * NU * T, *xo = a.x_out + b * 3 * W;
+    const bool st_u = live && !s.odd, st_x = live && s.odd;
+    if (st_x) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xo[r * W] = bad ? nan : x[r];
+    }
+    pair::NoStore ns;
+    double th = lp.theta0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const double w0 = s.odd ? s.wo[t] : s.ws[t], w1 = s.odd ? s.ws[t] : s.wo[t];
+        double u[4];
+        if (v.eq_mode == MPCX_EQ_NONE) { u[0] = w0; u[1] = w1; u[2] = 0.0; u[3] = 0.0; }
+        else if (v.eq_mode == MPCX_EQ_FIXED_STEER) { u[0] = w0; u[1] = v.steer_fixed; u[2] = w1; u[3] = v.steer_fixed; }
+        else { u[0] = w0; u[1] = w1; u[2] = w0; u[3] = sg * w1; }
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+            J = fma(v.R[r] * u[r], u[r], J);
+            if (t > 0) { const double d = u[r] - up[r]; J = fma(v.Rd[r] * d, d, J); }
+            up[r] = u[r];
+            if (st_u) uo[r * T + t] = bad ? nan : u[r];
+        }
+        double a02, a12, bt[3][2], ct[3];
+        stage_dynamics<MODEL, false>(ns, v, lp, t, th, a02, a12, bt, ct);
+        const double n0 = x[0] + a02 * x[2] + bt[0][0] * w0 + bt[0][1] * w1 + ct[0];
+        const double n1 = x[1] + a12 * x[2] + bt[1][0] * w0 + bt[1][1] * w1 + ct[1];
+        const double n2 = x[2] + bt[2][0] * w0 + bt[2][1] * w1 + ct[2];
+        x[0] = n0; x[1] = n1; x[2] = n2;
+        const int ts = t + 1;
+        if (ts < T) qg *= v.q_growth;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double e = xr[r * W + ts] - x[r];
+            const double q = ts < T ? v.Q[r] * qg : v.Qf[r];
+            J = fma(q * e, e, J);
+            if (st_x) xo[r * W + ts] = bad ? nan : x[r];
+        }
+    }
+    if (st_x) a.obj_out[b] = bad ? nan : J;
+    if (st_u) {
+        a.status_out[b] = status;
+        if (a.iters_out) a.iters_out[b] = iters;
+    }
 }
 
 template <int MODEL>
@@ -383,6 +508,9 @@ static bool all_present(const mpcx_variant *v)
 // the register-resident kernels are built for T = 5 with every bound present
 static bool uses_registers(const mpcx_variant *v) { return v->T == 5 && all_present(v); }
 
+// test hook: MPCX_SINGLE_LANE=1 routes T = 5 solves to the one-lane-per-instance kernel
+static const bool g_force_single_lane = [] { const char *e = getenv("MPCX_SINGLE_LANE"); return e && e[0] == '1'; }();
+
 // grow-only per-device workspace for the memory-resident path
 static std::mutex g_ws_mutex;
 static double *g_ws[64] = {nullptr};
@@ -403,6 +531,14 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
     if (uses_registers(v)) {
         const dim3 grid((unsigned)((a.B + kWave - 1) / kWave)), block(kWave);
         const bool chained = !a.linear_mode && v->chain > 1;
+        if (!chained && !g_force_single_lane) {
+            const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
+            if (v->model == MPCX_MODEL_DIFF_DRIVE) hipLaunchKernelGGL((k_solve_pair<0>), pgrid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_solve_pair<1>), pgrid, block, 0, st, a);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return hip_fail(e, "k_solve_pair launch");
+            return 0;
+        }
         if (v->model == MPCX_MODEL_DIFF_DRIVE) {
             if (chained) hipLaunchKernelGGL((k_solve_reg<0, 5, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((k_solve_reg<0, 5, false>), grid, block, 0, st, a);
