@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmpcx.so")
+# MPCX_LIB selects another build of the same library (kernel experiments); never a fallback
+LIB_PATH = os.environ.get("MPCX_LIB") or os.path.join(_HERE, "lib", "libmpcx.so")
 
 ABI_VERSION = 1
 

@@ -31,8 +31,14 @@ namespace mpcx {
 constexpr int kWave = 64;
 constexpr double kSlackMin = 1e-16;   // floor on a recomputed slack
 constexpr double kMu0 = 0.1;          // initial complementarity s*lambda
-constexpr double kTolD = 1e-8;        // relative stationarity
-constexpr double kTolMu = 1e-11;      // mean complementarity
+#ifndef MPCX_TOL_D
+#define MPCX_TOL_D 1e-8
+#endif
+#ifndef MPCX_TOL_MU
+#define MPCX_TOL_MU 1e-11
+#endif
+constexpr double kTolD = MPCX_TOL_D;    // relative stationarity
+constexpr double kTolMu = MPCX_TOL_MU;  // mean complementarity
 constexpr double kMuFloor = 1e-13;    // below this the recomputed slacks are rounding noise: stop
 constexpr double kLooseD = 1e-6;      // "inaccurate but accepted" thresholds
 constexpr double kLooseMu = 1e-7;
@@ -107,10 +113,30 @@ __device__ __forceinline__ void sincos_fast(double x, double &sn, double &cs)
 // Dual steer: mpc_dsr.py:397-426 entry by entry (B[2][0] uses sin(delta_r), B[1][3] has
 // the (sin dr cos th - cos dr sin th) pattern, C multiplies by (delta + theta): these are
 // the reference's formulas, not the analytic Jacobian) and :141-167 for the twist.
+// The part of the linearisation that depends on the controls only: sines and cosines of the
+// two steer angles (dual steer) and the yaw rate of the plant.
+struct SteerTerms {
+    double sf, cf, sr, cr, omega;
+};
+
 template <int MODEL>
-__device__ __forceinline__ void linearize(const mpcx_variant &v, double th, const double (&u)[4],
-                                          double &a02, double &a12, double (&Bm)[3][4],
-                                          double (&C)[3], double &omega)
+__device__ __forceinline__ void steer_terms(const mpcx_variant &v, const double (&u)[4], SteerTerms &k)
+{
+    if (MODEL == MPCX_MODEL_DIFF_DRIVE) {
+        k.sf = k.sr = 0.0;
+        k.cf = k.cr = 1.0;
+        k.omega = u[1];
+    } else {
+        sincos_fast(u[1], k.sf, k.cf);
+        sincos_fast(u[3], k.sr, k.cr);
+        k.omega = (k.sf * u[0] - k.sr * u[2]) / v.wb;
+    }
+}
+
+template <int MODEL>
+__device__ __forceinline__ void linearize_at(const mpcx_variant &v, double th, const double (&u)[4],
+                                             const SteerTerms &k, double &a02, double &a12,
+                                             double (&Bm)[3][4], double (&C)[3])
 {
     const double dt = v.dt;
     double st, ct;
@@ -118,7 +144,7 @@ __device__ __forceinline__ void linearize(const mpcx_variant &v, double th, cons
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Bm[r][k] = 0.0;
+        for (int c = 0; c < 4; ++c) Bm[r][c] = 0.0;
     if (MODEL == MPCX_MODEL_DIFF_DRIVE) {
         const double vr = u[0];
         a02 = -vr * st * dt;
@@ -129,13 +155,10 @@ __device__ __forceinline__ void linearize(const mpcx_variant &v, double th, cons
         C[0] = vr * st * th * dt;
         C[1] = -vr * ct * th * dt;
         C[2] = 0.0;
-        omega = u[1];
     } else {
         const double v_f = u[0], d_f = u[1], v_r = u[2], d_r = u[3];
-        double sf, cf, sr, cr;
-        sincos_fast(d_f, sf, cf);
-        sincos_fast(d_r, sr, cr);
-        const double h = 0.5 * dt, k = 1.0 / v.wb * dt;
+        const double sf = k.sf, cf = k.cf, sr = k.sr, cr = k.cr;
+        const double h = 0.5 * dt, kk = 1.0 / v.wb * dt;
         const double vc = v_f * cf + v_r * cr, vs = v_f * sf + v_r * sr;
         a02 = -0.5 * dt * vc * st - 0.5 * dt * vs * ct;
         a12 = 0.5 * dt * vc * ct - 0.5 * dt * vs * st;
@@ -147,15 +170,45 @@ __device__ __forceinline__ void linearize(const mpcx_variant &v, double th, cons
         Bm[1][1] = -h * (sf * st - cf * ct) * v_f;
         Bm[1][2] = h * (cr * st + sr * ct);
         Bm[1][3] = -h * (sr * ct - cr * st) * v_r;
-        Bm[2][0] = k * sr;
-        Bm[2][1] = k * cf * v_f;
-        Bm[2][2] = -k * sr;
-        Bm[2][3] = -k * cr * v_r;
+        Bm[2][0] = kk * sr;
+        Bm[2][1] = kk * cf * v_f;
+        Bm[2][2] = -kk * sr;
+        Bm[2][3] = -kk * cr * v_r;
         const double af = d_f + th, ar = d_r + th;
         C[0] = h * (v_f * cf * st * af + v_r * cr * st * ar + v_f * sf * ct * af + v_r * sr * ct * ar);
         C[1] = h * (-v_f * cf * ct * af - v_r * cr * ct * ar + v_f * sf * st * af + v_r * sr * st * ar);
-        C[2] = k * (-cf * d_f * v_f + cr * d_r * v_r);
-        omega = (sf * v_f - sr * v_r) / v.wb;
+        C[2] = kk * (-cf * d_f * v_f + cr * d_r * v_r);
+    }
+}
+
+template <int MODEL>
+__device__ __forceinline__ void linearize(const mpcx_variant &v, double th, const double (&u)[4],
+                                          double &a02, double &a12, double (&Bm)[3][4],
+                                          double (&C)[3], double &omega)
+{
+    SteerTerms k;
+    steer_terms<MODEL>(v, u, k);
+    linearize_at<MODEL>(v, th, u, k, a02, a12, Bm, C);
+    omega = k.omega;
+}
+
+// Reduced input matrix and offset of one stage under the variant's control equalities:
+// u = E w + f  =>  bt = Bm E,  ct = C + Bm f.
+__device__ __forceinline__ void reduce_controls(const mpcx_variant &v, const double (&Bm)[3][4],
+                                                const double (&C)[3], double (&bt)[3][2], double (&ct)[3])
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (v.eq_mode == MPCX_EQ_NONE) {
+            bt[r][0] = Bm[r][0]; bt[r][1] = Bm[r][1]; ct[r] = C[r];
+        } else if (v.eq_mode == MPCX_EQ_ACKERMANN) {
+            bt[r][0] = Bm[r][0] + Bm[r][2]; bt[r][1] = Bm[r][1] - Bm[r][3]; ct[r] = C[r];
+        } else if (v.eq_mode == MPCX_EQ_CRAB) {
+            bt[r][0] = Bm[r][0] + Bm[r][2]; bt[r][1] = Bm[r][1] + Bm[r][3]; ct[r] = C[r];
+        } else {
+            bt[r][0] = Bm[r][0]; bt[r][1] = Bm[r][2];
+            ct[r] = C[r] + (Bm[r][1] + Bm[r][3]) * v.steer_fixed;
+        }
     }
 }
 
@@ -384,19 +437,7 @@ __device__ __forceinline__ void stage_dynamics(S &s, const mpcx_variant &v, cons
     double Bm[3][4], C[3], omega;
     linearize<MODEL>(v, th, u, a02, a12, Bm, C, omega);
     th = th + omega * v.dt;   // used only when the yaw is rolled
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        if (v.eq_mode == MPCX_EQ_NONE) {
-            bt[r][0] = Bm[r][0]; bt[r][1] = Bm[r][1]; ct[r] = C[r];
-        } else if (v.eq_mode == MPCX_EQ_ACKERMANN) {
-            bt[r][0] = Bm[r][0] + Bm[r][2]; bt[r][1] = Bm[r][1] - Bm[r][3]; ct[r] = C[r];
-        } else if (v.eq_mode == MPCX_EQ_CRAB) {
-            bt[r][0] = Bm[r][0] + Bm[r][2]; bt[r][1] = Bm[r][1] + Bm[r][3]; ct[r] = C[r];
-        } else {
-            bt[r][0] = Bm[r][0]; bt[r][1] = Bm[r][2];
-            ct[r] = C[r] + (Bm[r][1] + Bm[r][3]) * v.steer_fixed;
-        }
-    }
+    reduce_controls(v, Bm, C, bt, ct);
 }
 
 // ------------------------------------------------------------------------------------

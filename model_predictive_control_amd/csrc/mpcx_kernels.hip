@@ -184,16 +184,47 @@ __global__ __launch_bounds__(kWave) void k_solve_reg(SolveArgs a)
     run_instance<MODEL, true, CHAIN>(s, a, b, live);
 }
 
+// Diagnostic builds (-DMPCX_STAMPS) record the shader clock at phase boundaries of the pair
+// kernel into a buffer nothing else reads; product builds contain no stamp.
+#ifdef MPCX_STAMPS
+constexpr int kStampWaves = 4096, kStampSlots = 8;
+__device__ unsigned long long g_stamps[kStampWaves * kStampSlots];
+#define MPCX_STAMP(k)                                                                         \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < kStampWaves)                                     \
+            g_stamps[blockIdx.x * kStampSlots + (k)] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
+#define MPCX_STAMP_CLEAR()                                                                    \
+    do {                                                                                      \
+        if (threadIdx.x < kStampSlots && blockIdx.x < kStampWaves)                            \
+            g_stamps[blockIdx.x * kStampSlots + threadIdx.x] = 0;                             \
+    } while (0)
+#else
+#define MPCX_STAMP(k)
+#define MPCX_STAMP_CLEAR()
+#endif
+
 // Two lanes per instance (T = 5, every bound present, single QP per call).
+#ifndef MPCX_PAIR_OCC
+#define MPCX_PAIR_OCC 1
+#endif
+#ifndef MPCX_PAIR_K
+#define MPCX_PAIR_K 5
+#endif
+constexpr int kPairIpmIters = MPCX_PAIR_K;   // interior-point iterations before the active-set rounds
+constexpr int kPairRounds0 = 6;              // active-set rounds after them
+constexpr int kPairRounds1 = 4;              // ... and after a converged interior-point solve
 template <int MODEL>
-__global__ __launch_bounds__(kWave, 2) void k_solve_pair(SolveArgs a)
+__global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a)
 {
     __shared__ double Hs[pair::kLdsPerLane * kWave];
+    __shared__ double Ds[pair::kDynDoubles * pair::kPairs];
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     constexpr int T = pair::TT, W = T + 1;
     const mpcx_variant &v = a.v;
     pair::State s;
     s.lds = (pair::lds_double *)Hs + threadIdx.x;
+    s.dyn = (pair::lds_double *)Ds + (threadIdx.x >> 1);
     const int64_t lane = (int64_t)blockIdx.x * kWave + threadIdx.x;
     s.odd = (lane & 1) != 0;
     int64_t b = lane >> 1;
@@ -230,7 +261,10 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_pair(SolveArgs a)
         x0[0] = x0[1] = x0[2] = 0.0;
         lp.theta0 = 0.0;
     }
+    MPCX_STAMP_CLEAR();
+    MPCX_STAMP(0);
     pair::assemble<MODEL>(s, v, lp, x0, xr);
+    MPCX_STAMP(1);
     {
         double u0[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -243,16 +277,25 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_pair(SolveArgs a)
         s.lo0 = s.odd ? fb.lo0[1] : fb.lo0[0];
         s.hi0 = s.odd ? fb.hi0[1] : fb.hi0[0];
     }
+    // Attempt 0: a fixed, wave-uniform number of interior-point iterations, then active-set
+    // rounds that either certify the exact optimum or give up.  Attempt 1 (only for lanes
+    // attempt 0 left unsettled): interior point to convergence, then the same rounds; if
+    // those do not settle either, the converged interior-point iterate is the answer.
     {
-        int st = MPCX_ST_OK, it = 0;
-        pair::ipm(s, a.max_iter, skip, st, it);
-        if (!skip) {
-            iters = it;
-            status = st;
-            if (st == MPCX_ST_FAILED) skip = true;
+        bool need = !skip;
+#pragma unroll 1
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int st = MPCX_ST_OK, it = 0;
+            pair::ipm(s, attempt == 0 ? (a.max_iter < kPairIpmIters ? a.max_iter : kPairIpmIters) : a.max_iter, !need, st, it);
+            MPCX_STAMP(2 + 2 * attempt);
+            if (need) { iters += it; status = st; }
+            const bool failed = need && attempt == 1 && st == MPCX_ST_FAILED;
+            const bool settled = pair::pdas(s, !need || failed, attempt == 0 ? kPairRounds0 : kPairRounds1);
+            MPCX_STAMP(3 + 2 * attempt);
+            if (need && settled) status = MPCX_ST_OK;
+            need = need && !settled;
+            if (!__any(need)) break;
         }
-        const bool polished = pair::polish(s, skip);
-        if (!skip && polished) status = MPCX_ST_OK;
     }
 
     // epilogue (both lanes evaluate it; the even lane stores the controls, the odd lane the states)
@@ -268,8 +311,6 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_pair(SolveArgs a)
 #pragma unroll
         for (int r = 0; r < 3; ++r) xo[r * W] = bad ? nan : x[r];
     }
-    pair::NoStore ns;
-    double th = lp.theta0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const double w0 = s.odd ? s.wo[t] : s.ws[t], w1 = s.odd ? s.ws[t] : s.wo[t];
@@ -284,8 +325,11 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_pair(SolveArgs a)
             up[r] = u[r];
             if (st_u) uo[r * T + t] = bad ? nan : u[r];
         }
-        double a02, a12, bt[3][2], ct[3];
-        stage_dynamics<MODEL, false>(ns, v, lp, t, th, a02, a12, bt, ct);
+        pair::Dyn dy;
+        pair::load_dyn(s, t, dy);
+        const double a02 = dy.a02, a12 = dy.a12;
+        const double (&bt)[3][2] = dy.bt;
+        const double (&ct)[3] = dy.ct;
         const double n0 = x[0] + a02 * x[2] + bt[0][0] * w0 + bt[0][1] * w1 + ct[0];
         const double n1 = x[1] + a12 * x[2] + bt[1][0] * w0 + bt[1][1] * w1 + ct[1];
         const double n2 = x[2] + bt[2][0] * w0 + bt[2][1] * w1 + ct[2];
@@ -305,6 +349,7 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_pair(SolveArgs a)
         a.status_out[b] = status;
         if (a.iters_out) a.iters_out[b] = iters;
     }
+    MPCX_STAMP(6);
 }
 
 template <int MODEL>
@@ -767,3 +812,13 @@ int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int
 }
 
 }  // extern "C"
+
+#ifdef MPCX_STAMPS
+extern "C" int mpcx_debug_stamps(unsigned long long *host, int n_waves)
+{
+    if (n_waves > mpcx::kStampWaves) n_waves = mpcx::kStampWaves;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mpcx::g_stamps), sizeof(unsigned long long) * n_waves * mpcx::kStampSlots)
+                   == hipSuccess ? n_waves : -1;
+}
+#endif

@@ -19,11 +19,18 @@
 namespace mpcx {
 namespace pair {
 
+#ifndef MPCX_PAIR_AUX
+#define MPCX_PAIR_AUX double
+#endif
+typedef MPCX_PAIR_AUX aux_t;             // storage type of the reciprocal slacks
 constexpr int TT = 5;                    // horizon = number of 2x2 block rows
 constexpr int NBLK = TT * (TT + 1) / 2;  // lower-triangular blocks
 constexpr int NRT = TT - 1;              // rate constraints per channel and side
 constexpr int kLdsPerLane = 2 * NBLK + TT;   // H same, H opp, g own
 constexpr double kInvM = 1.0 / (4.0 * TT + 4.0 * NRT);   // 36 constraints per instance
+constexpr int kDynPerStage = 11;             // a02, a12, bt[3][2], ct[3]
+constexpr int kDynDoubles = kDynPerStage * TT;
+constexpr int kPairs = kWave / 2;
 
 __device__ __forceinline__ constexpr int bi(int I, int J) { return I * (I + 1) / 2 + J; }
 
@@ -48,10 +55,11 @@ typedef __attribute__((address_space(3))) double lds_double;
 struct State {
     double S[NBLK], O[NBLK];                  // K, then its Cholesky factor (diagonal = 1/L_ii)
     double lamU[TT], lamL[TT], nuU[NRT], nuL[NRT];
-    float isu[TT], isl[TT], iru[NRT], irl[NRT];   // reciprocal slacks / dual steps / polish flags
+    aux_t isu[TT], isl[TT], iru[NRT], irl[NRT];   // reciprocal slacks / dual steps / polish flags
     double ws[TT], wo[TT];                    // own and partner controls
     double hw[TT], dwa[TT], dw[TT];           // own rows of H w + g (then predictor), corrector
     lds_double *lds;                          // [kLdsPerLane][64] + lane
+    lds_double *dyn;                          // [kDynDoubles][32] + pair: stage dynamics of the instance
     bool odd;
     double b, lo0, hi0, rr;                   // own channel's bounds
     __device__ __forceinline__ double HS(int I, int J) const { return ((const volatile lds_double *)lds)[bi(I, J) * kWave]; }
@@ -204,7 +212,7 @@ __device__ __forceinline__ void add_rate(State &s, int i, double d)
 // reductions are completed with the partner.
 __device__ __forceinline__ void ipm(State &s, int max_iter, bool skip, int &status, int &iters)
 {
-    {
+    if (!skip) {   // lanes that sit this solve out keep their controls
         const double wc = 0.5 * (s.lo0 + s.hi0);
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -215,9 +223,9 @@ __device__ __forceinline__ void ipm(State &s, int max_iter, bool skip, int &stat
         const double l0 = kMu0 * rcp_nr(s.rr);
 #pragma unroll
         for (int i = 0; i < NRT; ++i) { s.nuU[i] = l0; s.nuL[i] = l0; }
-#pragma unroll
-        for (int t = 0; t < TT; ++t) s.wo[t] = xchg(s.ws[t]);
     }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) s.wo[t] = xchg(s.ws[t]);
     bool done = skip;
     int my_iters = 0;
     status = MPCX_ST_FAILED;
@@ -228,7 +236,7 @@ __device__ __forceinline__ void ipm(State &s, int max_iter, bool skip, int &stat
         for (int t = 0; t < TT; ++t) {
             const double wi = s.ws[t];
             const double su = dmax(s.hi(t) - wi, kSlackMin), sl = dmax(wi - s.lo(t), kSlackMin);
-            const float fu = (float)rcp_raw(su), fl = (float)rcp_raw(sl);
+            const aux_t fu = (aux_t)rcp_raw(su), fl = (aux_t)rcp_raw(sl);
             s.isu[t] = fu; s.isl[t] = fl;
             const double lu = s.lamU[t], ll = s.lamL[t];
             add_box(s, t, fma(lu, (double)fu, ll * (double)fl));
@@ -239,7 +247,7 @@ __device__ __forceinline__ void ipm(State &s, int max_iter, bool skip, int &stat
         for (int i = 0; i < NRT; ++i) {
             const double dv = s.ws[i + 1] - s.ws[i];
             const double ru = dmax(s.rr - dv, kSlackMin), rl = dmax(s.rr + dv, kSlackMin);
-            const float fu = (float)rcp_raw(ru), fl = (float)rcp_raw(rl);
+            const aux_t fu = (aux_t)rcp_raw(ru), fl = (aux_t)rcp_raw(rl);
             s.iru[i] = fu; s.irl[i] = fl;
             const double nu = s.nuU[i], nl = s.nuL[i];
             add_rate(s, i, fma(nu, (double)fu, nl * (double)fl));
@@ -351,7 +359,7 @@ __device__ __forceinline__ void ipm(State &s, int max_iter, bool skip, int &stat
             const double dlu = fma(lu, zu, qu - lu), dll = fma(ll, zl, ql - ll);
             rp2 = dmax(rp2, dmax(zu, zl));
             rd2 = dmax(rd2, dmax(-dlu * rcp_raw(lu), -dll * rcp_raw(ll)));
-            s.isu[t] = (float)dlu; s.isl[t] = (float)dll;
+            s.isu[t] = (aux_t)dlu; s.isl[t] = (aux_t)dll;
         }
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
@@ -364,7 +372,7 @@ __device__ __forceinline__ void ipm(State &s, int max_iter, bool skip, int &stat
             const double dnu = fma(nu, zu, qu - nu), dnl = fma(nl, zl, ql - nl);
             rp2 = dmax(rp2, dmax(zu, zl));
             rd2 = dmax(rd2, dmax(-dnu * rcp_raw(nu), -dnl * rcp_raw(nl)));
-            s.iru[i] = (float)dnu; s.irl[i] = (float)dnl;
+            s.iru[i] = (aux_t)dnu; s.irl[i] = (aux_t)dnl;
         }
         rp2 = pair_max(rp2);
         rd2 = pair_max(rd2);
@@ -405,7 +413,7 @@ __device__ __forceinline__ bool polish(State &s, bool skip)
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             const double wi = s.ws[t], su = s.hi(t) - wi, sl = wi - s.lo(t);
-            float au, al;
+            aux_t au, al;
             if (round == 0) {
                 au = s.lamU[t] > su ? 1.f : 0.f;
                 al = s.lamL[t] > sl ? 1.f : 0.f;
@@ -420,7 +428,7 @@ __device__ __forceinline__ bool polish(State &s, bool skip)
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
             const double dv = s.ws[i + 1] - s.ws[i];
-            float au, al;
+            aux_t au, al;
             if (round == 0) {
                 au = s.nuU[i] > s.rr - dv ? 1.f : 0.f;
                 al = s.nuL[i] > s.rr + dv ? 1.f : 0.f;
@@ -520,18 +528,206 @@ __device__ __forceinline__ bool polish(State &s, bool skip)
     return accepted;
 }
 
-// Store stand-in for stage_dynamics<MODEL, false>: the linearisation point is read from
-// the caller's buffers, nothing is kept.
-struct NoStore {
-    double dummy_;
-    __device__ __forceinline__ int horizon() const { return TT; }
-    __device__ __forceinline__ double &uref(int, int) { return dummy_; }
-    __device__ __forceinline__ double &theta(int) { return dummy_; }
+// Primal-dual active-set rounds on the lane pair, started from an interior-point iterate
+// (constraints with multiplier > slack are taken as active).  Each round is one Newton step
+// of the augmented Lagrangian of the equality-constrained QP on the current set (factor of
+// H + rho A'A), a first-order multiplier update, and a correction of the set: multipliers
+// that turned negative leave, violated constraints enter.  A lane settles when its set
+// stood still over the last round and the point passes the KKT test of the original QP
+// (stationarity 1e-10 relative, feasibility and active-row residual 1e-12, multipliers
+// >= -1e-9 relative); rounds on an unchanged set are refinement steps, so a settled point
+// is exact to rounding.  Lanes in `skip` are left alone.  Returns true where the lane
+// settled; a lane that did not gets its controls back as they were on entry.
+__device__ __forceinline__ bool pdas(State &s, bool skip, int max_rounds)
+{
+    double hmax = 0.0, wbak[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) { hmax = dmax(hmax, s.HS(t, t)); wbak[t] = s.ws[t]; }
+    const double rho = 1e5 * pair_max(hmax);
+    // initial set from the interior-point iterate
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const double wi = s.ws[t];
+        const bool au = s.lamU[t] > s.hi(t) - wi, al = s.lamL[t] > wi - s.lo(t);
+        s.isu[t] = au ? 1.0 : 0.0; s.isl[t] = al ? 1.0 : 0.0;
+        s.lamU[t] = au ? s.lamU[t] : 0.0; s.lamL[t] = al ? s.lamL[t] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NRT; ++i) {
+        const double dv = s.ws[i + 1] - s.ws[i];
+        const bool au = s.nuU[i] > s.rr - dv, al = s.nuL[i] > s.rr + dv;
+        s.iru[i] = au ? 1.0 : 0.0; s.irl[i] = al ? 1.0 : 0.0;
+        s.nuU[i] = au ? s.nuU[i] : 0.0; s.nuL[i] = al ? s.nuL[i] : 0.0;
+    }
+    bool settled = skip, accepted = false, changed = true;
+    double scale = 1.0;
+#pragma unroll 1
+    for (int round = 0;; ++round) {
+        matvec<true>(s);
+        double viol = 0.0, cact = 0.0, neg = 0.0, stat = 0.0;
+        double gl[TT], ga[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const double wi = s.ws[t], vu = wi - s.hi(t), vl = s.lo(t) - wi;
+            const double au = (double)s.isu[t], al = (double)s.isl[t];
+            const double cu = au * vu, cl = al * vl;
+            const double t1 = s.lamU[t] - s.lamL[t];
+            gl[t] = s.hw[t] + t1;
+            ga[t] = rho * (cu - cl);
+            viol = dmax(viol, dmax(vu, vl));
+            cact = dmax(cact, dmax(fabs(cu), fabs(cl)));
+            neg = dmax(neg, dmax(-s.lamU[t], -s.lamL[t]));
+            add_box(s, t, rho * (au + al));
+        }
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const double dv = s.ws[i + 1] - s.ws[i], vu = dv - s.rr, vl = -dv - s.rr;
+            const double au = (double)s.iru[i], al = (double)s.irl[i];
+            const double cu = au * vu, cl = al * vl;
+            const double t1 = s.nuU[i] - s.nuL[i];
+            gl[i + 1] += t1; gl[i] -= t1;
+            const double ta = rho * (cu - cl);
+            ga[i + 1] += ta; ga[i] -= ta;
+            viol = dmax(viol, dmax(vu, vl));
+            cact = dmax(cact, dmax(fabs(cu), fabs(cl)));
+            neg = dmax(neg, dmax(-s.nuU[i], -s.nuL[i]));
+            add_rate(s, i, rho * (au + al));
+        }
+        scale = 1.0;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            stat = dmax(stat, fabs(gl[t]));
+            const double gi = s.g(t);
+            scale = dmax(scale, dmax(fabs(gi), fabs(s.hw[t] - gi)));
+        }
+        stat = pair_max(stat); viol = pair_max(viol); cact = pair_max(cact); neg = pair_max(neg);
+        scale = pair_max(scale) + 1.0;
+        if (!settled && !changed && stat <= 1e-10 * scale && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) {
+            settled = true;
+            accepted = true;
+        }
+        if (round >= max_rounds || __all(settled)) break;
+
+        chol(s);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) s.dw[t] = -(gl[t] + ga[t]);
+        solve(s, s.dw);
+        const double ntol = -1e-9 * scale;
+        bool ch = false;
+        if (!settled) {
+#pragma unroll
+            for (int t = 0; t < TT; ++t) s.ws[t] += s.dw[t];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                const double wi = s.ws[t], vu = wi - s.hi(t), vl = s.lo(t) - wi;
+                const bool au = s.isu[t] != 0, al = s.isl[t] != 0;
+                const double lu = au ? fma(rho, vu, s.lamU[t]) : 0.0, ll = al ? fma(rho, vl, s.lamL[t]) : 0.0;
+                const bool nu = (au && lu >= ntol) || vu > 1e-12, nl = (al && ll >= ntol) || vl > 1e-12;
+                ch = ch || nu != au || nl != al;
+                s.isu[t] = nu ? 1.0 : 0.0; s.isl[t] = nl ? 1.0 : 0.0;
+                s.lamU[t] = nu ? dmax(lu, 0.0) : 0.0; s.lamL[t] = nl ? dmax(ll, 0.0) : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NRT; ++i) {
+                const double dv = s.ws[i + 1] - s.ws[i], vu = dv - s.rr, vl = -dv - s.rr;
+                const bool au = s.iru[i] != 0, al = s.irl[i] != 0;
+                const double lu = au ? fma(rho, vu, s.nuU[i]) : 0.0, ll = al ? fma(rho, vl, s.nuL[i]) : 0.0;
+                const bool nu = (au && lu >= ntol) || vu > 1e-12, nl = (al && ll >= ntol) || vl > 1e-12;
+                ch = ch || nu != au || nl != al;
+                s.iru[i] = nu ? 1.0 : 0.0; s.irl[i] = nl ? 1.0 : 0.0;
+                s.nuU[i] = nu ? dmax(lu, 0.0) : 0.0; s.nuL[i] = nl ? dmax(ll, 0.0) : 0.0;
+            }
+        }
+        // the partner's channel belongs to the same QP: the set moved if either half did
+        changed = __builtin_amdgcn_mov_dpp((int)ch, 0xB1, 0xF, 0xF, true) != 0 || ch;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) s.wo[t] = xchg(s.ws[t]);
+    }
+    if (!accepted && !skip) {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) s.ws[t] = wbak[t];
+    }
+#pragma unroll
+    for (int t = 0; t < TT; ++t) s.wo[t] = xchg(s.ws[t]);
+    return accepted;
+}
+
+// Reduced dynamics of one stage:  x+ = (I + a02 e0 e2' + a12 e1 e2') x + bt w_t + ct.
+struct Dyn {
+    double a02, a12, bt[3][2], ct[3];
 };
 
+__device__ __forceinline__ void load_dyn(const State &s, int t, Dyn &d)
+{
+    const volatile lds_double *p = (const volatile lds_double *)s.dyn + t * kDynPerStage * kPairs;
+    d.a02 = p[0];
+    d.a12 = p[kPairs];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        d.bt[r][0] = p[(2 + 2 * r) * kPairs];
+        d.bt[r][1] = p[(3 + 2 * r) * kPairs];
+        d.ct[r] = p[(8 + r) * kPairs];
+    }
+}
+
+// Stage dynamics of the instance into LDS, the five stages split between the two lanes
+// (even lane: stages 0, 2, 4; odd lane: 1, 3 and 4 again, writing the same numbers).  The
+// yaw of the linearisation points is rolled from the yaw rates exactly as predict_motion
+// does (mpc_diff_drive.py:126-139), the rates of the partner's stages arriving by DPP.
+template <int MODEL>
+__device__ __forceinline__ void stage_split(State &s, const mpcx_variant &v, const LinPoint &lp)
+{
+    constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
+    const bool odd = s.odd;
+    double u[3][4], th[3];
+    SteerTerms k[3];
+    int tj[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int t = 2 * j + (odd ? 1 : 0);
+        t = t < TT ? t : TT - 1;
+        tj[j] = t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[j][r] = 0.0;
+#pragma unroll
+        for (int r = 0; r < NU; ++r) u[j][r] = lp.u ? lp.u[r * TT + t] : lp.cold[r];
+        steer_terms<MODEL>(v, u[j], k[j]);
+    }
+    if (lp.yaw) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) th[j] = lp.yaw[tj[j]];
+    } else {
+        const double w0 = from_even(k[0].omega), w1 = from_odd(k[0].omega);
+        const double w2 = from_even(k[1].omega), w3 = from_odd(k[1].omega);
+        const double t0 = lp.theta0;
+        const double t1 = t0 + w0 * v.dt;
+        const double t2 = t1 + w1 * v.dt;
+        const double t3 = t2 + w2 * v.dt;
+        const double t4 = t3 + w3 * v.dt;
+        th[0] = odd ? t1 : t0;
+        th[1] = odd ? t3 : t2;
+        th[2] = t4;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double a02, a12, Bm[3][4], C[3], bt[3][2], ct[3];
+        linearize_at<MODEL>(v, th[j], u[j], k[j], a02, a12, Bm, C);
+        reduce_controls(v, Bm, C, bt, ct);
+        volatile lds_double *p = (volatile lds_double *)s.dyn + tj[j] * kDynPerStage * kPairs;
+        p[0] = a02;
+        p[kPairs] = a12;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            p[(2 + 2 * r) * kPairs] = bt[r][0];
+            p[(3 + 2 * r) * kPairs] = bt[r][1];
+            p[(8 + r) * kPairs] = ct[r];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();   // one wave: LDS keeps program order, the compiler must too
+}
+
 // Condensed Hessian rows and gradient entries of the lane's channel, straight into LDS.
-// Both lanes of a pair evaluate the stage dynamics (they need all of G); each accumulates
-// only its own rows of H.
+// The stage dynamics come from LDS (stage_split); each lane accumulates its own rows of H.
 template <int MODEL>
 __device__ __forceinline__ void assemble(State &s, const mpcx_variant &v, const LinPoint &lp,
                                          const double (&x0)[3], const double *__restrict__ xref)
@@ -565,13 +761,16 @@ __device__ __forceinline__ void assemble(State &s, const mpcx_variant &v, const 
         s.S[bi(t, t)] = d;
         if (t > 0) s.S[bi(t, t - 1)] = -2.0 * rdc;
     }
-    NoStore ns;
+    stage_split<MODEL>(s, v, lp);
     double p[3] = {x0[0], x0[1], x0[2]};
-    double qg = 1.0, th = lp.theta0;
+    double qg = 1.0;
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
-        double a02, a12, bt[3][2], ct[3];
-        stage_dynamics<MODEL, false>(ns, v, lp, t, th, a02, a12, bt, ct);
+        Dyn dy;
+        load_dyn(s, t, dy);
+        const double a02 = dy.a02, a12 = dy.a12;
+        const double (&bt)[3][2] = dy.bt;
+        const double (&ct)[3] = dy.ct;
         const double pn0 = p[0] + a02 * p[2] + ct[0];
         const double pn1 = p[1] + a12 * p[2] + ct[1];
         const double pn2 = p[2] + ct[2];

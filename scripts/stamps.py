@@ -1,0 +1,34 @@
+"""Phase timing of the pair kernel from a -DMPCX_STAMPS build (MPCX_LIB points at it)."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from model_predictive_control_amd import engine, variants, workload, _lib
+name = sys.argv[1] if len(sys.argv) > 1 else "dsr_ackermann"
+B = 65536
+v = variants.get(name)
+courses = workload.make_courses(64)
+inst = workload.make_instances(courses, B, seed=2003)
+xref = torch.from_numpy(workload.reference_window(courses, inst, v.T)).cuda()
+x0 = torch.from_numpy(inst["state"][:, :3].copy()).cuda()
+out = engine.solve_batch(v, x0, xref)
+up = out["u"].clone()
+for _ in range(3):
+    out = engine.solve_batch(v, x0, xref, up)
+torch.cuda.synchronize()
+lib = _lib.load()
+n = 2048
+buf = (C.c_ulonglong * (n * 8))()
+lib.mpcx_debug_stamps.restype = C.c_int
+lib.mpcx_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+assert lib.mpcx_debug_stamps(C.cast(buf, C.c_void_p), n) == n
+st = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
+its = out["iters"].cpu().numpy().reshape(-1, 32).max(1)[:n]
+print("wave iters (max over 32 instances): mean", its.mean(), "instance mean", out["iters"].float().mean().item(),
+      "status counts", np.bincount(out["status"].cpu().numpy(), minlength=5))
+fb = st[:, 5] > 0
+end_solve = np.where(fb, st[:, 5], st[:, 3])
+ph = {"assemble": st[:, 1] - st[:, 0], "ipm0": st[:, 2] - st[:, 1], "pdas0": st[:, 3] - st[:, 2],
+      "fallback": np.where(fb, st[:, 5] - st[:, 3], 0), "epilogue": st[:, 6] - end_solve, "total": st[:, 6] - st[:, 0]}
+print("waves taking the fallback:", int(fb.sum()), "of", n)
+for nm, d in ph.items():
+    print(f"{nm:9s} median {np.median(d):9.0f} mean {d.mean():9.0f} cycles")
