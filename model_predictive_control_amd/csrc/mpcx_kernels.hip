@@ -10,6 +10,30 @@
 
 #include "mpcx.h"
 #include "mpcx_device.h"
+
+namespace mpcx {
+// Diagnostic builds (-DMPCX_STAMPS) record the shader clock at phase boundaries of the pair
+// kernel into a buffer nothing else reads; product builds contain no stamp.
+#ifdef MPCX_STAMPS
+constexpr int kStampWaves = 4096, kStampSlots = 16;
+__device__ unsigned long long g_stamps[kStampWaves * kStampSlots];
+#define MPCX_STAMP(k)                                                                         \
+    do {                                                                                      \
+        if (threadIdx.x == 0 && blockIdx.x < kStampWaves)                                     \
+            g_stamps[blockIdx.x * kStampSlots + (k)] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
+#define MPCX_STAMP_CLEAR()                                                                    \
+    do {                                                                                      \
+        if (threadIdx.x < kStampSlots && blockIdx.x < kStampWaves)                            \
+            g_stamps[blockIdx.x * kStampSlots + threadIdx.x] = 0;                             \
+    } while (0)
+#else
+#define MPCX_STAMP(k)
+#define MPCX_STAMP_CLEAR()
+#endif
+
+}  // namespace mpcx
+
 #include "mpcx_pair.h"
 
 namespace mpcx {
@@ -184,26 +208,6 @@ __global__ __launch_bounds__(kWave) void k_solve_reg(SolveArgs a)
     run_instance<MODEL, true, CHAIN>(s, a, b, live);
 }
 
-// Diagnostic builds (-DMPCX_STAMPS) record the shader clock at phase boundaries of the pair
-// kernel into a buffer nothing else reads; product builds contain no stamp.
-#ifdef MPCX_STAMPS
-constexpr int kStampWaves = 4096, kStampSlots = 8;
-__device__ unsigned long long g_stamps[kStampWaves * kStampSlots];
-#define MPCX_STAMP(k)                                                                         \
-    do {                                                                                      \
-        if (threadIdx.x == 0 && blockIdx.x < kStampWaves)                                     \
-            g_stamps[blockIdx.x * kStampSlots + (k)] = __builtin_amdgcn_s_memtime();          \
-    } while (0)
-#define MPCX_STAMP_CLEAR()                                                                    \
-    do {                                                                                      \
-        if (threadIdx.x < kStampSlots && blockIdx.x < kStampWaves)                            \
-            g_stamps[blockIdx.x * kStampSlots + threadIdx.x] = 0;                             \
-    } while (0)
-#else
-#define MPCX_STAMP(k)
-#define MPCX_STAMP_CLEAR()
-#endif
-
 // Two lanes per instance (T = 5, every bound present, single QP per call).
 #ifndef MPCX_PAIR_OCC
 #define MPCX_PAIR_OCC 1
@@ -217,42 +221,72 @@ constexpr int kPairRounds1 = 4;              // ... and after a converged interi
 template <int MODEL>
 __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a)
 {
+    // LDS: Hs = input staging (x0, controls, xbar), then H and g, then output staging;
+    // Ds = stage dynamics; Xs = the wave's reference windows (read again by the epilogue)
     __shared__ double Hs[pair::kLdsPerLane * kWave];
     __shared__ double Ds[pair::kDynDoubles * pair::kPairs];
+    __shared__ double Xs[pair::kPairs * 3 * (pair::TT + 1)];
+    __shared__ int Fs[kWave];
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     constexpr int T = pair::TT, W = T + 1;
+    constexpr int kInU = pair::kPairs * 3, kInXbar = kInU + pair::kPairs * NU * T;
+    static_assert(kInXbar + pair::kPairs * 3 * W <= pair::kLdsPerLane * kWave, "input staging must fit in the H area");
     const mpcx_variant &v = a.v;
     pair::State s;
-    s.lds = (pair::lds_double *)Hs + threadIdx.x;
-    s.dyn = (pair::lds_double *)Ds + (threadIdx.x >> 1);
-    const int64_t lane = (int64_t)blockIdx.x * kWave + threadIdx.x;
-    s.odd = (lane & 1) != 0;
-    int64_t b = lane >> 1;
-    const bool live = b < a.B;
-    if (!live) b = a.B - 1;   // idle pairs redo the last instance so wave votes stay uniform
+    const int lane = threadIdx.x;
+    MPCX_STAMP_CLEAR();
+    MPCX_STAMP(0);
+    s.bind((pair::lds_double *)Hs, (pair::lds_double *)Ds, lane);
+    const int64_t b0 = (int64_t)blockIdx.x * pair::kPairs;
+    const int nb = a.B - b0 < pair::kPairs ? (int)(a.B - b0) : pair::kPairs;
+    const int pl = lane >> 1;
+    const bool live = pl < nb;
+    const int pc = live ? pl : nb - 1;   // idle pairs redo the wave's last instance so votes stay uniform
+    const int64_t b = b0 + pc;
 
-    const double *__restrict__ xr = a.xref + b * 3 * W;
-    double x0[3] = {a.x0[b * 3], a.x0[b * 3 + 1], a.x0[b * 3 + 2]};
-    bool finite = finite_d(x0[0]) && finite_d(x0[1]) && finite_d(x0[2]);
-#pragma unroll
-    for (int i = 0; i < 3 * W; ++i) finite = finite && finite_d(xr[i]);
-    const double *uin = a.uin ? a.uin + b * NU * T : nullptr;
-    const bool warm = a.linear_mode || (uin && (!a.has_prev || a.has_prev[b]));
-    LinPoint lp;
-    lp.u = warm ? uin : nullptr;
-    lp.cold = v.cold_start;
-    lp.yaw = nullptr;
-    lp.theta0 = x0[2];
-    if (a.linear_mode) {
-        const double *xb = a.xbar + b * 3 * W;
-#pragma unroll
-        for (int i = 0; i < 3 * W; ++i) finite = finite && finite_d(xb[i]);
-        lp.yaw = xb + 2 * W;
+    pair::lds_double *stg = (pair::lds_double *)Hs, *xs = (pair::lds_double *)Xs;
+    // non-finite input raises a per-instance flag while it is staged: [0..31] state, reference
+    // and xbar; [32..63] controls (which only count for warm-started instances)
+    volatile __attribute__((address_space(3))) int *flg = (volatile __attribute__((address_space(3))) int *)Fs;
+    flg[lane] = 0;
+    bool warm;
+    {
+        pair::StageIn<pair::kPairs * 3 * W, 3 * W> in_xr, in_xb;
+        pair::StageIn<pair::kPairs * 3, 3> in_x0;
+        pair::StageIn<pair::kPairs * NU * T, NU * T> in_u;
+        in_xr.load(a.xref + b0 * 3 * W, nb * 3 * W, lane);
+        in_x0.load(a.x0 + b0 * 3, nb * 3, lane);
+        if (a.uin) in_u.load(a.uin + b0 * NU * T, nb * NU * T, lane);
+        if (a.linear_mode) in_xb.load(a.xbar + b0 * 3 * W, nb * 3 * W, lane);
+        warm = a.linear_mode || (a.uin && (!a.has_prev || a.has_prev[b]));
+        in_xr.put(nb * 3 * W, xs, lane, flg);
+        in_x0.put(nb * 3, stg, lane, flg);
+        if (a.uin) in_u.put(nb * NU * T, stg + kInU, lane, flg + pair::kPairs);
+        if (a.linear_mode) in_xb.put(nb * 3 * W, stg + kInXbar, lane, flg);
     }
+    __builtin_amdgcn_wave_barrier();
+
+    const volatile pair::lds_double *xr = xs + pc * 3 * W;
+    const volatile pair::lds_double *x0s = stg + pc * 3;
+    double x0[3] = {x0s[0], x0s[1], x0s[2]};
+#ifdef MPCX_STAMPS
+    if (x0[0] == 1.2345e300) return;   // forces the loads to have landed before the stamp
+#endif
+    MPCX_STAMP(8);
+    bool coldfin = true;
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int r = 0; r < NU; ++r) coldfin = coldfin && finite_d(v.cold_start[r]);
+    const bool finite = flg[pc] == 0 && (warm ? flg[pair::kPairs + pc] == 0 : coldfin);
+    pair::Lin lp;
+    lp.u = stg + kInU + pc * NU * T;
+    lp.cold = v.cold_start;
+    lp.warm = warm;
+    lp.has_yaw = a.linear_mode != 0;
+    lp.yaw = stg + kInXbar + pc * 3 * W + 2 * W;
+    lp.theta0 = x0[2];
+    double u0[4] = {0.0, 0.0, 0.0, 0.0};   // first-stage controls: read before H overwrites the staging
 #pragma unroll
-        for (int r = 0; r < NU; ++r) finite = finite && finite_d(lp.u ? lp.u[r * T + t] : lp.cold[r]);
+    for (int r = 0; r < NU; ++r) u0[r] = lp.control(r, 0);
 
     int status = MPCX_ST_OK, iters = 0;
     bool skip = !finite;
@@ -261,18 +295,14 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
         x0[0] = x0[1] = x0[2] = 0.0;
         lp.theta0 = 0.0;
     }
-    MPCX_STAMP_CLEAR();
-    MPCX_STAMP(0);
+    MPCX_STAMP(9);
     pair::assemble<MODEL>(s, v, lp, x0, xr);
     MPCX_STAMP(1);
     {
-        double u0[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int r = 0; r < NU; ++r) u0[r] = lp.u ? lp.u[r * T] : lp.cold[r];
         FreeBounds fb;
         free_bounds(v, u0, fb);
         if (!fb.feasible && !skip) { skip = true; status = MPCX_ST_INFEASIBLE; }
-        s.b = s.odd ? fb.b[1] : fb.b[0];
+        s.b_ = s.odd ? fb.b[1] : fb.b[0];
         s.rr = s.odd ? fb.rr[1] : fb.rr[0];
         s.lo0 = s.odd ? fb.lo0[1] : fb.lo0[0];
         s.hi0 = s.odd ? fb.hi0[1] : fb.hi0[0];
@@ -286,11 +316,17 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; ++attempt) {
             int st = MPCX_ST_OK, it = 0;
-            pair::ipm(s, attempt == 0 ? (a.max_iter < kPairIpmIters ? a.max_iter : kPairIpmIters) : a.max_iter, !need, st, it);
+            pair::ipm(s, attempt == 0 ? (a.max_iter < kPairIpmIters ? a.max_iter : kPairIpmIters) : a.max_iter, attempt == 0, !need, st, it);
             MPCX_STAMP(2 + 2 * attempt);
             if (need) { iters += it; status = st; }
             const bool failed = need && attempt == 1 && st == MPCX_ST_FAILED;
+#ifdef MPCX_STAMPS
+            int rounds = 0;
+            const bool settled = pair::pdas(s, !need || failed, attempt == 0 ? kPairRounds0 : kPairRounds1, &rounds);
+            if (attempt == 0 && threadIdx.x == 0 && blockIdx.x < kStampWaves) g_stamps[blockIdx.x * kStampSlots + 7] = rounds;
+#else
             const bool settled = pair::pdas(s, !need || failed, attempt == 0 ? kPairRounds0 : kPairRounds1);
+#endif
             MPCX_STAMP(3 + 2 * attempt);
             if (need && settled) status = MPCX_ST_OK;
             need = need && !settled;
@@ -298,15 +334,17 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
         }
     }
 
-    // epilogue (both lanes evaluate it; the even lane stores the controls, the odd lane the states)
+    // epilogue (both lanes evaluate it; the even lane stages the controls, the odd lane the
+    // states and the objective; the wave then writes its 32 records as contiguous blocks)
     const bool bad = status == MPCX_ST_NONFINITE || status == MPCX_ST_INFEASIBLE;
     const double nan = __builtin_nan("");
     const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
     double J = 0.0, qg = 1.0;
     double x[3] = {x0[0], x0[1], x0[2]};
     double up[4] = {0, 0, 0, 0};
-    double *uo = a.u_out + b * NU * T, *xo = a.x_out + b * 3 * W;
-    const bool st_u = live && !s.odd, st_x = live && s.odd;
+    constexpr int kOutX = pair::kPairs * NU * T, kOutJ = kOutX + pair::kPairs * 3 * W;
+    volatile pair::lds_double *uo = stg + pl * NU * T, *xo = stg + kOutX + pl * 3 * W;
+    const bool st_u = !s.odd, st_x = s.odd;
     if (st_x) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) xo[r * W] = bad ? nan : x[r];
@@ -344,8 +382,12 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
             if (st_x) xo[r * W + ts] = bad ? nan : x[r];
         }
     }
-    if (st_x) a.obj_out[b] = bad ? nan : J;
-    if (st_u) {
+    if (st_x) ((volatile pair::lds_double *)stg)[kOutJ + pl] = bad ? nan : J;
+    __builtin_amdgcn_wave_barrier();
+    pair::stage_out<pair::kPairs * NU * T>(a.u_out + b0 * NU * T, nb * NU * T, stg, lane);
+    pair::stage_out<pair::kPairs * 3 * W>(a.x_out + b0 * 3 * W, nb * 3 * W, stg + kOutX, lane);
+    pair::stage_out<pair::kPairs>(a.obj_out + b0, nb, stg + kOutJ, lane);
+    if (live && !s.odd) {
         a.status_out[b] = status;
         if (a.iters_out) a.iters_out[b] = iters;
     }

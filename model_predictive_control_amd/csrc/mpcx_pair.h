@@ -3,16 +3,21 @@
 // The condensed QP has 2 free controls per stage; variable 2t + c belongs to channel c.
 // Lane parity c owns channel c: its five controls, its box and rate constraints (all of
 // them couple controls of one channel only), and rows 2t + c of the symmetric matrices.
-// That halves the per-lane state (~150 registers instead of > 500), so two waves fit on
-// a SIMD and nothing spills.  Matrices are stored by 2x2 blocks (I, J), J <= I, two
-// entries per block and lane, in parity-relative order:
-//     S[I][J] = M(2I + c, 2J + c)        "same-parity column"
-//     O[I][J] = M(2I + c, 2J + 1 - c)    "opposite-parity column"
-// With this order the trailing update of the Cholesky factorisation, the triangular solves
-// and the matrix-vector product run the same instruction stream on both lanes; partner
-// values travel by DPP quad permutes (no LDS, no divergence).  For the even lane O[I][I]
-// is the mirror of the odd lane's sub-diagonal entry: it is kept consistent but never read
-// as part of the factor.
+// That halves the per-lane state, so the whole solve stays in registers with nothing
+// spilled to memory.  Partner values travel by DPP quad permutes (no LDS, no divergence).
+//
+// H (constant over the solve) lives in LDS by 2x2 blocks (I, J), J <= I, two entries per
+// block and lane, in parity-relative order:
+//     HS[I][J] = H(2I + c, 2J + c)        "same-parity column"
+//     HO[I][J] = H(2I + c, 2J + 1 - c)    "opposite-parity column"
+// so that the matrix-vector product runs one instruction stream on both lanes.
+//
+// K = H + barrier terms and its Cholesky factor live in registers in column-absolute order
+// (E = even column 2J, D = odd column 2J + 1 of the lane's rows), which a lane reads from
+// LDS through a parity-dependent base address.  The factorisation works by 2x2 blocks: the
+// diagonal block is factored on both lanes redundantly, the panel below it is local to the
+// row owner, and only the panel entries the trailing update needs cross the pair; no
+// select on the lane parity is left in the factorisation or in the triangular solves.
 #pragma once
 #include "mpcx_device.h"
 
@@ -25,6 +30,7 @@ namespace pair {
 typedef MPCX_PAIR_AUX aux_t;             // storage type of the reciprocal slacks
 constexpr int TT = 5;                    // horizon = number of 2x2 block rows
 constexpr int NBLK = TT * (TT + 1) / 2;  // lower-triangular blocks
+constexpr int NOFF = TT * (TT - 1) / 2;  // blocks strictly below the diagonal
 constexpr int NRT = TT - 1;              // rate constraints per channel and side
 constexpr int kLdsPerLane = 2 * NBLK + TT;   // H same, H opp, g own
 constexpr double kInvM = 1.0 / (4.0 * TT + 4.0 * NRT);   // 36 constraints per instance
@@ -32,7 +38,8 @@ constexpr int kDynPerStage = 11;             // a02, a12, bt[3][2], ct[3]
 constexpr int kDynDoubles = kDynPerStage * TT;
 constexpr int kPairs = kWave / 2;
 
-__device__ __forceinline__ constexpr int bi(int I, int J) { return I * (I + 1) / 2 + J; }
+__device__ __forceinline__ constexpr int bi(int I, int J) { return I * (I + 1) / 2 + J; }   // J <= I
+__device__ __forceinline__ constexpr int oi(int I, int J) { return I * (I - 1) / 2 + J; }   // J <  I
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_double(double x)
@@ -53,20 +60,40 @@ __device__ __forceinline__ double pair_max(double x) { return dmax(x, xchg(x)); 
 typedef __attribute__((address_space(3))) double lds_double;
 
 struct State {
-    double S[NBLK], O[NBLK];                  // K, then its Cholesky factor (diagonal = 1/L_ii)
+    // K, then its factor.  Blocks below the diagonal: E[I][J] = K(2I + c, 2J), D[I][J] =
+    // K(2I + c, 2J + 1).  Diagonal block I: d = the lane's own diagonal entry, b = the entry
+    // coupling rows 2I and 2I + 1 (kept identical on both lanes).
+    double E[NOFF], D[NOFF], d[TT], b[TT];
+    // factor of the diagonal blocks, identical on both lanes:
+    // 1 / L(2I, 2I), L(2I + 1, 2I), 1 / L(2I + 1, 2I + 1)
+    double r0[TT], l10[TT], r1[TT];
     double lamU[TT], lamL[TT], nuU[NRT], nuL[NRT];
-    aux_t isu[TT], isl[TT], iru[NRT], irl[NRT];   // reciprocal slacks / dual steps / polish flags
+    aux_t isu[TT], isl[TT], iru[NRT], irl[NRT];   // reciprocal slacks / dual steps / active-set flags
     double ws[TT], wo[TT];                    // own and partner controls
     double hw[TT], dwa[TT], dw[TT];           // own rows of H w + g (then predictor), corrector
     lds_double *lds;                          // [kLdsPerLane][64] + lane
+    lds_double *ldsE, *ldsD;                  // where this lane finds its even / odd column blocks of H
     lds_double *dyn;                          // [kDynDoubles][32] + pair: stage dynamics of the instance
     bool odd;
-    double b, lo0, hi0, rr;                   // own channel's bounds
+    double mE, mO;                            // 1 on the even / odd lane, 0 on the other
+    double b_, lo0, hi0, rr;                  // own channel's bounds
+    __device__ __forceinline__ void bind(lds_double *base, lds_double *dynbase, int lane)
+    {
+        odd = (lane & 1) != 0;
+        lds = base + lane;
+        ldsE = lds + (odd ? NBLK * kWave : 0);
+        ldsD = lds + (odd ? 0 : NBLK * kWave);
+        dyn = dynbase + (lane >> 1);
+        mE = odd ? 0.0 : 1.0;
+        mO = odd ? 1.0 : 0.0;
+    }
     __device__ __forceinline__ double HS(int I, int J) const { return ((const volatile lds_double *)lds)[bi(I, J) * kWave]; }
     __device__ __forceinline__ double HO(int I, int J) const { return ((const volatile lds_double *)lds)[(NBLK + bi(I, J)) * kWave]; }
+    __device__ __forceinline__ double HE_(int I, int J) const { return ((const volatile lds_double *)ldsE)[bi(I, J) * kWave]; }
+    __device__ __forceinline__ double HD_(int I, int J) const { return ((const volatile lds_double *)ldsD)[bi(I, J) * kWave]; }
     __device__ __forceinline__ double g(int I) const { return ((const volatile lds_double *)lds)[(2 * NBLK + I) * kWave]; }
-    __device__ __forceinline__ double hi(int t) const { return t == 0 ? hi0 : b; }
-    __device__ __forceinline__ double lo(int t) const { return t == 0 ? lo0 : -b; }
+    __device__ __forceinline__ double hi(int t) const { return t == 0 ? hi0 : b_; }
+    __device__ __forceinline__ double lo(int t) const { return t == 0 ? lo0 : -b_; }
 };
 
 // hw <- own rows of H w + g; optionally K <- H on the way.
@@ -83,77 +110,60 @@ __device__ __forceinline__ void matvec(State &s)
 #pragma unroll
         for (int J = 0; J < I; ++J) {
             const double hs = s.HS(I, J), ho = s.HO(I, J);
-            if (COPY_K) { s.S[bi(I, J)] = hs; s.O[bi(I, J)] = ho; }
             acc = fma(hs, s.ws[J], acc);
             acc = fma(ho, s.wo[J], acc);
             tS[J] = fma(hs, wi, tS[J]);   // column of my parity: one of my own rows
             tO[J] = fma(ho, wi, tO[J]);   // column of the other parity: a row of the partner
         }
         const double hd = s.HS(I, I), hx = s.HO(I, I);
-        if (COPY_K) { s.S[bi(I, I)] = hd; s.O[bi(I, I)] = hx; }
+        if (COPY_K) { s.d[I] = hd; s.b[I] = hx; }
         acc = fma(hd, wi, acc);
         acc = fma(hx, s.wo[I], acc);
         s.hw[I] = acc;
     }
 #pragma unroll
     for (int J = 0; J < TT - 1; ++J) s.hw[J] += tS[J] + xchg(tO[J]);
+    if (COPY_K) {
+#pragma unroll
+        for (int I = 1; I < TT; ++I) {
+#pragma unroll
+            for (int J = 0; J < I; ++J) { s.E[oi(I, J)] = s.HE_(I, J); s.D[oi(I, J)] = s.HD_(I, J); }
+        }
+    }
 }
 
-// In-place Cholesky of the pair-distributed matrix; S[I][I] ends up as 1 / L_ii of the
-// lane's own diagonal entry.
+// In-place Cholesky of the pair-distributed matrix, by 2x2 blocks.
 __device__ __forceinline__ void chol(State &s)
 {
-    const bool odd = s.odd;
 #pragma unroll
     for (int J = 0; J < TT; ++J) {
-        {   // pivot column 2J (the even lane's diagonal)
-            const double r = rsqrt_nr(from_even(s.S[bi(J, J)]));
-            const double rs = odd ? 1.0 : r, ro = odd ? r : 1.0;   // which of my slots is that column
-            double own[TT], oth[TT];
+        const double a = from_even(s.d[J]), c = from_odd(s.d[J]);
+        const double r0 = rsqrt_nr(a);
+        const double l10 = s.b[J] * r0;
+        const double r1 = rsqrt_nr(fma(-l10, l10, c));
+        s.r0[J] = r0; s.l10[J] = l10; s.r1[J] = r1;
+        double Le[TT], Ld[TT], cEe[TT], cEd[TT], cOe[TT], cOd[TT];
 #pragma unroll
-            for (int I = J + 1; I < TT; ++I) {
-                s.S[bi(I, J)] *= rs;
-                s.O[bi(I, J)] *= ro;
-                own[I] = odd ? s.O[bi(I, J)] : s.S[bi(I, J)];
-            }
-            const double lJ = s.O[bi(J, J)] * r;   // odd lane: L(2J+1, 2J)
-            s.O[bi(J, J)] = lJ;
-            s.S[bi(J, J)] = odd ? s.S[bi(J, J)] : r;
-            own[J] = odd ? lJ : 0.0;               // the pivot row itself takes no update
-#pragma unroll
-            for (int I = J; I < TT; ++I) oth[I] = xchg(own[I]);
-#pragma unroll
-            for (int I = J; I < TT; ++I) {
-                const double li = own[I];
-#pragma unroll
-                for (int K = J; K <= I; ++K) {
-                    s.S[bi(I, K)] = fma(-li, own[K], s.S[bi(I, K)]);
-                    s.O[bi(I, K)] = fma(-li, oth[K], s.O[bi(I, K)]);
-                }
-            }
+        for (int I = J + 1; I < TT; ++I) {   // panel: local to the row owner
+            Le[I] = s.E[oi(I, J)] * r0;
+            Ld[I] = fma(-Le[I], l10, s.D[oi(I, J)]) * r1;
+            s.E[oi(I, J)] = Le[I];
+            s.D[oi(I, J)] = Ld[I];
         }
-        {   // pivot column 2J + 1 (the odd lane's diagonal)
-            const double r = rsqrt_nr(from_odd(s.S[bi(J, J)]));
-            const double rs = odd ? r : 1.0, ro = odd ? 1.0 : r;
-            double own[TT], oth[TT];
 #pragma unroll
-            for (int I = J + 1; I < TT; ++I) {
-                s.S[bi(I, J)] *= rs;
-                s.O[bi(I, J)] *= ro;
-                own[I] = odd ? s.S[bi(I, J)] : s.O[bi(I, J)];
+        for (int K = J + 1; K < TT; ++K) {   // panel rows 2K (even lane) and 2K + 1 (odd lane)
+            cEe[K] = from_even(Le[K]); cEd[K] = from_even(Ld[K]);
+            cOe[K] = from_odd(Le[K]);  cOd[K] = from_odd(Ld[K]);
+        }
+#pragma unroll
+        for (int I = J + 1; I < TT; ++I) {
+#pragma unroll
+            for (int K = J + 1; K < I; ++K) {
+                s.E[oi(I, K)] = fma(-Le[I], cEe[K], fma(-Ld[I], cEd[K], s.E[oi(I, K)]));
+                s.D[oi(I, K)] = fma(-Le[I], cOe[K], fma(-Ld[I], cOd[K], s.D[oi(I, K)]));
             }
-            s.S[bi(J, J)] = odd ? r : s.S[bi(J, J)];
-#pragma unroll
-            for (int I = J + 1; I < TT; ++I) oth[I] = xchg(own[I]);
-#pragma unroll
-            for (int I = J + 1; I < TT; ++I) {
-                const double li = own[I];
-#pragma unroll
-                for (int K = J + 1; K <= I; ++K) {
-                    s.S[bi(I, K)] = fma(-li, own[K], s.S[bi(I, K)]);
-                    s.O[bi(I, K)] = fma(-li, oth[K], s.O[bi(I, K)]);
-                }
-            }
+            s.d[I] = fma(-Le[I], Le[I], fma(-Ld[I], Ld[I], s.d[I]));
+            s.b[I] = fma(-cEe[I], cOe[I], fma(-cEd[I], cOd[I], s.b[I]));
         }
     }
 }
@@ -161,56 +171,52 @@ __device__ __forceinline__ void chol(State &s)
 // r (own rows) <- own rows of K^-1 r, using the factor left by chol().
 __device__ __forceinline__ void solve(const State &s, double (&r)[TT])
 {
-    const bool odd = s.odd;
-    double ys[TT], yo[TT];
+    double yE[TT], yO[TT];
 #pragma unroll
     for (int I = 0; I < TT; ++I) {
         double acc = r[I];
 #pragma unroll
         for (int J = 0; J < I; ++J) {
-            acc = fma(-s.S[bi(I, J)], ys[J], acc);
-            acc = fma(-s.O[bi(I, J)], yo[J], acc);
+            acc = fma(-s.E[oi(I, J)], yE[J], acc);
+            acc = fma(-s.D[oi(I, J)], yO[J], acc);
         }
-        const double d = s.S[bi(I, I)];
-        const double yE = from_even(acc * d);                       // row 2I
-        const double yO = from_odd(fma(-s.O[bi(I, I)], yE, acc) * d);   // row 2I + 1
-        ys[I] = odd ? yO : yE;
-        yo[I] = odd ? yE : yO;
+        const double aE = from_even(acc), aO = from_odd(acc);
+        yE[I] = aE * s.r0[I];
+        yO[I] = fma(-s.l10[I], yE[I], aO) * s.r1[I];
     }
-    double zs[TT];
 #pragma unroll
     for (int kk = 0; kk < TT; ++kk) {
         const int K = TT - 1 - kk;
-        double sumS = 0.0, sumO = 0.0;
+        double sE = 0.0, sO = 0.0;
 #pragma unroll
         for (int I = K + 1; I < TT; ++I) {
-            sumS = fma(s.S[bi(I, K)], zs[I], sumS);
-            sumO = fma(s.O[bi(I, K)], zs[I], sumO);
+            sE = fma(s.E[oi(I, K)], r[I], sE);
+            sO = fma(s.D[oi(I, K)], r[I], sO);
         }
-        const double d = s.S[bi(K, K)];
-        // column 2K + 1: the odd lane's same-parity entries, the even lane's opposite ones
-        const double zO = from_odd((ys[K] - pair_sum(odd ? sumS : sumO)) * d);
-        // column 2K: plus the odd lane's sub-diagonal entry of this block
-        const double zE = from_even((ys[K] - pair_sum(odd ? fma(s.O[bi(K, K)], zO, sumO) : sumS)) * d);
-        zs[K] = odd ? zO : zE;
+        if (K < TT - 1) { sE = pair_sum(sE); sO = pair_sum(sO); }
+        const double zO = (yO[K] - sO) * s.r1[K];
+        const double zE = fma(-s.l10[K], zO, yE[K] - sE) * s.r0[K];
+        r[K] = s.odd ? zO : zE;
     }
-#pragma unroll
-    for (int I = 0; I < TT; ++I) r[I] = zs[I];
 }
 
 // K <- K + (diagonal and same-channel sub-diagonal barrier terms); everything is local.
-__device__ __forceinline__ void add_box(State &s, int t, double d) { s.S[bi(t, t)] += d; }
-__device__ __forceinline__ void add_rate(State &s, int i, double d)
+__device__ __forceinline__ void add_box(State &s, int t, double dd) { s.d[t] += dd; }
+__device__ __forceinline__ void add_rate(State &s, int i, double dd)
 {
-    s.S[bi(i, i)] += d;
-    s.S[bi(i + 1, i + 1)] += d;
-    s.S[bi(i + 1, i)] -= d;
+    s.d[i] += dd;
+    s.d[i + 1] += dd;
+    // K(2(i+1) + c, 2i + c): the even lane's even column, the odd lane's odd column
+    s.E[oi(i + 1, i)] = fma(-s.mE, dd, s.E[oi(i + 1, i)]);
+    s.D[oi(i + 1, i)] = fma(-s.mO, dd, s.D[oi(i + 1, i)]);
 }
 
 // Mehrotra predictor-corrector on the lane pair.  See ipm_solve() in mpcx_device.h for the
 // formulas; here every constraint loop runs over the lane's own channel and the scalar
 // reductions are completed with the partner.
-__device__ __forceinline__ void ipm(State &s, int max_iter, bool skip, int &status, int &iters)
+// `fixed`: run exactly max_iter iterations (no pass is spent on a convergence test after the
+// last one); lanes that have not converged by then report MPCX_ST_FAILED.
+__device__ __forceinline__ void ipm(State &s, int max_iter, bool fixed, bool skip, int &status, int &iters)
 {
     if (!skip) {   // lanes that sit this solve out keep their controls
         const double wc = 0.5 * (s.lo0 + s.hi0);
@@ -230,6 +236,10 @@ __device__ __forceinline__ void ipm(State &s, int max_iter, bool skip, int &stat
     int my_iters = 0;
     status = MPCX_ST_FAILED;
     for (int it = 0;; ++it) {
+        if (fixed && it >= max_iter) {
+            if (!done) my_iters = it;
+            break;
+        }
         matvec<true>(s);
         double musum = 0.0, ctl[TT];
 #pragma unroll
@@ -300,26 +310,9 @@ __device__ __forceinline__ void ipm(State &s, int max_iter, bool skip, int &stat
         rdm = pair_max(rdm);
         const double apa = rp > 1.0 ? rcp_nr(rp) : 1.0;
         const double ada = rcp_nr(rdm);
-        double muaff = 0.0;
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            const double wi = s.ws[t], d = s.dwa[t];
-            const double su = dmax(s.hi(t) - wi, kSlackMin), sl = dmax(wi - s.lo(t), kSlackMin);
-            const double xu = d * (double)s.isu[t], xl = -d * (double)s.isl[t];
-            muaff += (su * fma(-apa, xu, 1.0)) * (s.lamU[t] * fma(ada, xu - 1.0, 1.0));
-            muaff += (sl * fma(-apa, xl, 1.0)) * (s.lamL[t] * fma(ada, xl - 1.0, 1.0));
-        }
-#pragma unroll
-        for (int i = 0; i < NRT; ++i) {
-            const double dv = s.ws[i + 1] - s.ws[i], d = s.dwa[i + 1] - s.dwa[i];
-            const double ru = dmax(s.rr - dv, kSlackMin), rl = dmax(s.rr + dv, kSlackMin);
-            const double yu = d * (double)s.iru[i], yl = -d * (double)s.irl[i];
-            muaff += (ru * fma(-apa, yu, 1.0)) * (s.nuU[i] * fma(ada, yu - 1.0, 1.0));
-            muaff += (rl * fma(-apa, yl, 1.0)) * (s.nuL[i] * fma(ada, yl - 1.0, 1.0));
-        }
-        muaff = pair_sum(muaff) * kInvM;
-        const double ratio = muaff * rcp_nr(dmax(mu, 1e-300));
-        const double sm = ratio * ratio * ratio * mu;   // sigma * mu
+        // centring from the predictor's step lengths alone: sigma = (1 - alpha_aff)^3
+        const double back = 1.0 - dmin(apa, ada);
+        const double sm = back * back * back * mu;   // sigma * mu
 
         // corrector as a correction to the predictor: K (dw - dwa) = -C' q
 #pragma unroll
@@ -398,136 +391,6 @@ __device__ __forceinline__ void ipm(State &s, int max_iter, bool skip, int &stat
     iters = my_iters;
 }
 
-// Active-set polish on the lane pair (see polish() in mpcx_device.h).
-__device__ __forceinline__ bool polish(State &s, bool skip)
-{
-    double hmax = 0.0, wbak[TT];
-#pragma unroll
-    for (int t = 0; t < TT; ++t) { hmax = dmax(hmax, s.HS(t, t)); wbak[t] = s.ws[t]; }
-    const double rho = 1e5 * pair_max(hmax);
-    bool accepted = false, settled = skip;
-    double scale = 1.0;
-#pragma unroll 1
-    for (int round = 0; round < kPolishRounds; ++round) {
-        const double ntol = -1e-9 * scale;
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            const double wi = s.ws[t], su = s.hi(t) - wi, sl = wi - s.lo(t);
-            aux_t au, al;
-            if (round == 0) {
-                au = s.lamU[t] > su ? 1.f : 0.f;
-                al = s.lamL[t] > sl ? 1.f : 0.f;
-            } else {
-                au = ((s.isu[t] != 0.f && s.lamU[t] >= ntol) || su < -1e-12) ? 1.f : 0.f;
-                al = ((s.isl[t] != 0.f && s.lamL[t] >= ntol) || sl < -1e-12) ? 1.f : 0.f;
-            }
-            s.isu[t] = au; s.isl[t] = al;
-            s.lamU[t] = (double)au * dmax(s.lamU[t], 0.0);
-            s.lamL[t] = (double)al * dmax(s.lamL[t], 0.0);
-        }
-#pragma unroll
-        for (int i = 0; i < NRT; ++i) {
-            const double dv = s.ws[i + 1] - s.ws[i];
-            aux_t au, al;
-            if (round == 0) {
-                au = s.nuU[i] > s.rr - dv ? 1.f : 0.f;
-                al = s.nuL[i] > s.rr + dv ? 1.f : 0.f;
-            } else {
-                au = ((s.iru[i] != 0.f && s.nuU[i] >= ntol) || s.rr - dv < -1e-12) ? 1.f : 0.f;
-                al = ((s.irl[i] != 0.f && s.nuL[i] >= ntol) || s.rr + dv < -1e-12) ? 1.f : 0.f;
-            }
-            s.iru[i] = au; s.irl[i] = al;
-            s.nuU[i] = (double)au * dmax(s.nuU[i], 0.0);
-            s.nuL[i] = (double)al * dmax(s.nuL[i], 0.0);
-        }
-        // K = H + rho A'A on the active rows
-#pragma unroll
-        for (int I = 0; I < TT; ++I) {
-#pragma unroll
-            for (int J = 0; J <= I; ++J) { s.S[bi(I, J)] = s.HS(I, J); s.O[bi(I, J)] = s.HO(I, J); }
-        }
-#pragma unroll
-        for (int t = 0; t < TT; ++t) add_box(s, t, rho * (double)(s.isu[t] + s.isl[t]));
-#pragma unroll
-        for (int i = 0; i < NRT; ++i) add_rate(s, i, rho * (double)(s.iru[i] + s.irl[i]));
-        chol(s);
-
-        double stat = 0.0;
-#pragma unroll 1
-        for (int pass = 0; pass < 3; ++pass) {
-            matvec<false>(s);
-            double gl[TT];   // gradient of the Lagrangian; hw becomes that of the augmented one
-#pragma unroll
-            for (int t = 0; t < TT; ++t) {
-                const double wi = s.ws[t];
-                const double cu = (double)s.isu[t] * (wi - s.hi(t)), cl = (double)s.isl[t] * (s.lo(t) - wi);
-                if (pass > 0) { s.lamU[t] = fma(rho, cu, s.lamU[t]); s.lamL[t] = fma(rho, cl, s.lamL[t]); }
-                const double t1 = s.lamU[t] - s.lamL[t];
-                gl[t] = s.hw[t] + t1;
-                s.hw[t] += t1 + rho * (cu - cl);
-            }
-#pragma unroll
-            for (int i = 0; i < NRT; ++i) {
-                const double dv = s.ws[i + 1] - s.ws[i];
-                const double cu = (double)s.iru[i] * (dv - s.rr), cl = (double)s.irl[i] * (-dv - s.rr);
-                if (pass > 0) { s.nuU[i] = fma(rho, cu, s.nuU[i]); s.nuL[i] = fma(rho, cl, s.nuL[i]); }
-                const double t1 = s.nuU[i] - s.nuL[i];
-                gl[i + 1] += t1; gl[i] -= t1;
-                const double ta = t1 + rho * (cu - cl);
-                s.hw[i + 1] += ta; s.hw[i] -= ta;
-            }
-            stat = 0.0; scale = 1.0;
-#pragma unroll
-            for (int t = 0; t < TT; ++t) {
-                stat = dmax(stat, fabs(gl[t]));
-                scale = dmax(scale, dmax(fabs(s.g(t)), fabs(gl[t] - s.hw[t])));
-            }
-            stat = pair_max(stat);
-            scale = pair_max(scale) + 1.0;
-            if (pass == 2) break;
-#pragma unroll
-            for (int t = 0; t < TT; ++t) s.hw[t] = -s.hw[t];
-            solve(s, s.hw);
-            if (!settled) {
-#pragma unroll
-                for (int t = 0; t < TT; ++t) s.ws[t] += s.hw[t];
-            }
-#pragma unroll
-            for (int t = 0; t < TT; ++t) s.wo[t] = xchg(s.ws[t]);
-        }
-        double viol = 0.0, neg = 0.0, far = 0.0, cact = 0.0;
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            const double wi = s.ws[t];
-            far = dmax(far, fabs(wi - wbak[t]));
-            viol = dmax(viol, dmax(wi - s.hi(t), s.lo(t) - wi));
-            cact = dmax(cact, dmax((double)s.isu[t] * fabs(wi - s.hi(t)), (double)s.isl[t] * fabs(s.lo(t) - wi)));
-            neg = dmax(neg, dmax(-s.lamU[t], -s.lamL[t]));
-        }
-#pragma unroll
-        for (int i = 0; i < NRT; ++i) {
-            const double dv = s.ws[i + 1] - s.ws[i];
-            viol = dmax(viol, dmax(dv - s.rr, -dv - s.rr));
-            cact = dmax(cact, dmax((double)s.iru[i] * fabs(dv - s.rr), (double)s.irl[i] * fabs(-dv - s.rr)));
-            neg = dmax(neg, dmax(-s.nuU[i], -s.nuL[i]));
-        }
-        viol = pair_max(viol); neg = pair_max(neg); far = pair_max(far); cact = pair_max(cact);
-        if (!settled) {
-            const bool sane = stat <= 1e-10 * scale && far <= 1e-3;
-            if (sane && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) { accepted = true; settled = true; }
-            else if (!sane) settled = true;
-        }
-        if (__all(settled)) break;
-    }
-    if (!accepted) {
-#pragma unroll
-        for (int t = 0; t < TT; ++t) s.ws[t] = wbak[t];
-#pragma unroll
-        for (int t = 0; t < TT; ++t) s.wo[t] = xchg(s.ws[t]);
-    }
-    return accepted;
-}
-
 // Primal-dual active-set rounds on the lane pair, started from an interior-point iterate
 // (constraints with multiplier > slack are taken as active).  Each round is one Newton step
 // of the augmented Lagrangian of the equality-constrained QP on the current set (factor of
@@ -538,7 +401,7 @@ __device__ __forceinline__ bool polish(State &s, bool skip)
 // >= -1e-9 relative); rounds on an unchanged set are refinement steps, so a settled point
 // is exact to rounding.  Lanes in `skip` are left alone.  Returns true where the lane
 // settled; a lane that did not gets its controls back as they were on entry.
-__device__ __forceinline__ bool pdas(State &s, bool skip, int max_rounds)
+__device__ __forceinline__ bool pdas(State &s, bool skip, int max_rounds, int *rounds_done = nullptr)
 {
     double hmax = 0.0, wbak[TT];
 #pragma unroll
@@ -606,7 +469,10 @@ __device__ __forceinline__ bool pdas(State &s, bool skip, int max_rounds)
             settled = true;
             accepted = true;
         }
-        if (round >= max_rounds || __all(settled)) break;
+        if (round >= max_rounds || __all(settled)) {
+            if (rounds_done) *rounds_done = round;
+            break;
+        }
 
         chol(s);
 #pragma unroll
@@ -652,6 +518,69 @@ __device__ __forceinline__ bool pdas(State &s, bool skip, int max_rounds)
     return accepted;
 }
 
+// Contiguous block of n doubles between global memory and LDS, 512 bytes per wave
+// instruction (the wave's 32 instance records lie back to back in every API array).
+// load(): every lane fetches its doubles of the block (indices past the end are clamped, so
+// all lanes load from valid addresses and nothing waits on a branch); put(): into LDS.  The
+// caller issues the loads of all its blocks before the first put, so the wave pays one memory
+// round trip.  A value that is not finite raises the flag of the instance record it belongs
+// to (PER doubles each).
+template <int MAXN, int PER>
+struct StageIn {
+    static constexpr int K = (MAXN + kWave - 1) / kWave;
+    double tmp[K];
+    __device__ __forceinline__ void load(const double *__restrict__ g, int n, int lane)
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = lane + k * kWave;
+            tmp[k] = g[i < n ? i : n - 1];
+        }
+    }
+    __device__ __forceinline__ void put(int n, lds_double *dst, int lane,
+                                        volatile __attribute__((address_space(3))) int *flag) const
+    {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int i = lane + k * kWave;
+            if (i < n) {
+                ((volatile lds_double *)dst)[i] = tmp[k];
+                if (!finite_d(tmp[k])) flag[i / PER] = 1;
+            }
+        }
+    }
+};
+template <int MAXN>
+__device__ __forceinline__ void stage_out(double *__restrict__ g, int n, const lds_double *src, int lane)
+{
+    constexpr int K = (MAXN + kWave - 1) / kWave;
+    double tmp[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = lane + k * kWave;
+        tmp[k] = ((const volatile lds_double *)src)[i < MAXN ? i : MAXN - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = lane + k * kWave;
+        if (i < n) g[i] = tmp[k];
+    }
+}
+
+// Linearisation point of one instance, read from the wave's LDS staging area.
+struct Lin {
+    const volatile lds_double *u;     // [NU][T] (always a readable address)
+    const volatile lds_double *yaw;   // xbar[2][0..T-1] when given
+    const double *cold;               // v.cold_start
+    bool warm, has_yaw;
+    double theta0;
+    __device__ __forceinline__ double control(int r, int t) const
+    {
+        const double x = u[r * TT + t];
+        return warm ? x : cold[r];
+    }
+};
+
 // Reduced dynamics of one stage:  x+ = (I + a02 e0 e2' + a12 e1 e2') x + bt w_t + ct.
 struct Dyn {
     double a02, a12, bt[3][2], ct[3];
@@ -675,7 +604,7 @@ __device__ __forceinline__ void load_dyn(const State &s, int t, Dyn &d)
 // yaw of the linearisation points is rolled from the yaw rates exactly as predict_motion
 // does (mpc_diff_drive.py:126-139), the rates of the partner's stages arriving by DPP.
 template <int MODEL>
-__device__ __forceinline__ void stage_split(State &s, const mpcx_variant &v, const LinPoint &lp)
+__device__ __forceinline__ void stage_split(State &s, const mpcx_variant &v, const Lin &lp)
 {
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     const bool odd = s.odd;
@@ -690,10 +619,10 @@ __device__ __forceinline__ void stage_split(State &s, const mpcx_variant &v, con
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[j][r] = 0.0;
 #pragma unroll
-        for (int r = 0; r < NU; ++r) u[j][r] = lp.u ? lp.u[r * TT + t] : lp.cold[r];
+        for (int r = 0; r < NU; ++r) u[j][r] = lp.control(r, t);
         steer_terms<MODEL>(v, u[j], k[j]);
     }
-    if (lp.yaw) {
+    if (lp.has_yaw) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) th[j] = lp.yaw[tj[j]];
     } else {
@@ -729,8 +658,8 @@ __device__ __forceinline__ void stage_split(State &s, const mpcx_variant &v, con
 // Condensed Hessian rows and gradient entries of the lane's channel, straight into LDS.
 // The stage dynamics come from LDS (stage_split); each lane accumulates its own rows of H.
 template <int MODEL>
-__device__ __forceinline__ void assemble(State &s, const mpcx_variant &v, const LinPoint &lp,
-                                         const double (&x0)[3], const double *__restrict__ xref)
+__device__ __forceinline__ void assemble(State &s, const mpcx_variant &v, const Lin &lp,
+                                         const double (&x0)[3], const volatile lds_double *xref)
 {
     constexpr int W = TT + 1;
     const bool odd = s.odd;
@@ -744,11 +673,11 @@ __device__ __forceinline__ void assemble(State &s, const mpcx_variant &v, const 
         rdw[0] = v.Rd[0] + v.Rd[2]; rdw[1] = v.Rd[1] + v.Rd[3];
     }
     const double rwc = odd ? rw[1] : rw[0], rdc = odd ? rdw[1] : rdw[0];
-    double GS[3][TT], GO[3][TT], gacc[TT];
+    double GS[3][TT], GO[3][TT], gacc[TT], HSa[NBLK], HOa[NBLK];
 #pragma unroll
     for (int I = 0; I < TT; ++I) {
 #pragma unroll
-        for (int J = 0; J <= I; ++J) { s.S[bi(I, J)] = 0.0; s.O[bi(I, J)] = 0.0; }
+        for (int J = 0; J <= I; ++J) { HSa[bi(I, J)] = 0.0; HOa[bi(I, J)] = 0.0; }
         gacc[I] = 0.0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) { GS[r][I] = 0.0; GO[r][I] = 0.0; }
@@ -758,10 +687,13 @@ __device__ __forceinline__ void assemble(State &s, const mpcx_variant &v, const 
         double d = 2.0 * rwc;
         if (t > 0) d += 2.0 * rdc;
         if (t + 1 < TT) d += 2.0 * rdc;
-        s.S[bi(t, t)] = d;
-        if (t > 0) s.S[bi(t, t - 1)] = -2.0 * rdc;
+        HSa[bi(t, t)] = d;
+        if (t > 0) HSa[bi(t, t - 1)] = -2.0 * rdc;
     }
     stage_split<MODEL>(s, v, lp);
+#ifdef MPCX_STAMP
+    MPCX_STAMP(10);
+#endif
     double p[3] = {x0[0], x0[1], x0[2]};
     double qg = 1.0;
 #pragma unroll
@@ -807,14 +739,14 @@ __device__ __forceinline__ void assemble(State &s, const mpcx_variant &v, const 
                 gacc[I] = fma(gi, e, gacc[I]);
 #pragma unroll
                 for (int J = 0; J <= I; ++J) {
-                    s.S[bi(I, J)] = fma(gi, GS[r][J], s.S[bi(I, J)]);
-                    s.O[bi(I, J)] = fma(gi, GO[r][J], s.O[bi(I, J)]);
+                    HSa[bi(I, J)] = fma(gi, GS[r][J], HSa[bi(I, J)]);
+                    HOa[bi(I, J)] = fma(gi, GO[r][J], HOa[bi(I, J)]);
                 }
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < NBLK; ++e) { s.lds[e * kWave] = s.S[e]; s.lds[(NBLK + e) * kWave] = s.O[e]; }
+    for (int e = 0; e < NBLK; ++e) { s.lds[e * kWave] = HSa[e]; s.lds[(NBLK + e) * kWave] = HOa[e]; }
 #pragma unroll
     for (int I = 0; I < TT; ++I) s.lds[(2 * NBLK + I) * kWave] = gacc[I];
 }

@@ -17,18 +17,19 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib = _lib.load()
 n = 2048
-buf = (C.c_ulonglong * (n * 8))()
+buf = (C.c_ulonglong * (n * 16))()
 lib.mpcx_debug_stamps.restype = C.c_int
 lib.mpcx_debug_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.mpcx_debug_stamps(C.cast(buf, C.c_void_p), n) == n
-st = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
+st = np.frombuffer(buf, dtype=np.uint64).reshape(n, 16).astype(np.int64)
 its = out["iters"].cpu().numpy().reshape(-1, 32).max(1)[:n]
 print("wave iters (max over 32 instances): mean", its.mean(), "instance mean", out["iters"].float().mean().item(),
       "status counts", np.bincount(out["status"].cpu().numpy(), minlength=5))
 fb = st[:, 5] > 0
 end_solve = np.where(fb, st[:, 5], st[:, 3])
-ph = {"assemble": st[:, 1] - st[:, 0], "ipm0": st[:, 2] - st[:, 1], "pdas0": st[:, 3] - st[:, 2],
+ph = {"load": st[:, 8] - st[:, 0], "checks": st[:, 9] - st[:, 8], "stage_split": st[:, 10] - st[:, 9], "condense": st[:, 1] - st[:, 10], "ipm0": st[:, 2] - st[:, 1], "pdas0": st[:, 3] - st[:, 2],
       "fallback": np.where(fb, st[:, 5] - st[:, 3], 0), "epilogue": st[:, 6] - end_solve, "total": st[:, 6] - st[:, 0]}
+print("active-set rounds per wave: mean", st[:, 7].mean(), "hist", np.bincount(st[:, 7].astype(int)))
 print("waves taking the fallback:", int(fb.sum()), "of", n)
 for nm, d in ph.items():
     print(f"{nm:9s} median {np.median(d):9.0f} mean {d.mean():9.0f} cycles")
