@@ -225,12 +225,13 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
     // Ds = stage dynamics; Xs = the wave's reference windows (read again by the epilogue)
     __shared__ double Hs[pair::kLdsPerLane * kWave];
     __shared__ double Ds[pair::kDynDoubles * pair::kPairs];
-    __shared__ double Xs[pair::kPairs * 3 * (pair::TT + 1)];
+    __shared__ double Xs[pair::kPairs * pair::padded(3 * (pair::TT + 1))];
     __shared__ int Fs[kWave];
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     constexpr int T = pair::TT, W = T + 1;
-    constexpr int kInU = pair::kPairs * 3, kInXbar = kInU + pair::kPairs * NU * T;
-    static_assert(kInXbar + pair::kPairs * 3 * W <= pair::kLdsPerLane * kWave, "input staging must fit in the H area");
+    constexpr int SX = pair::padded(3 * W), SU = pair::padded(NU * T), S0 = pair::padded(3);   // record strides in LDS
+    constexpr int kInU = pair::kPairs * S0, kInXbar = kInU + pair::kPairs * SU;
+    static_assert(kInXbar + pair::kPairs * SX <= pair::kLdsPerLane * kWave, "input staging must fit in the H area");
     const mpcx_variant &v = a.v;
     pair::State s;
     const int lane = threadIdx.x;
@@ -266,8 +267,8 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
     }
     __builtin_amdgcn_wave_barrier();
 
-    const volatile pair::lds_double *xr = xs + pc * 3 * W;
-    const volatile pair::lds_double *x0s = stg + pc * 3;
+    const volatile pair::lds_double *xr = xs + pc * SX;
+    const volatile pair::lds_double *x0s = stg + pc * S0;
     double x0[3] = {x0s[0], x0s[1], x0s[2]};
 #ifdef MPCX_STAMPS
     if (x0[0] == 1.2345e300) return;   // forces the loads to have landed before the stamp
@@ -278,11 +279,11 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
     for (int r = 0; r < NU; ++r) coldfin = coldfin && finite_d(v.cold_start[r]);
     const bool finite = flg[pc] == 0 && (warm ? flg[pair::kPairs + pc] == 0 : coldfin);
     pair::Lin lp;
-    lp.u = stg + kInU + pc * NU * T;
+    lp.u = stg + kInU + pc * SU;
     lp.cold = v.cold_start;
     lp.warm = warm;
     lp.has_yaw = a.linear_mode != 0;
-    lp.yaw = stg + kInXbar + pc * 3 * W + 2 * W;
+    lp.yaw = stg + kInXbar + pc * SX + 2 * W;
     lp.theta0 = x0[2];
     double u0[4] = {0.0, 0.0, 0.0, 0.0};   // first-stage controls: read before H overwrites the staging
 #pragma unroll
@@ -342,8 +343,8 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
     double J = 0.0, qg = 1.0;
     double x[3] = {x0[0], x0[1], x0[2]};
     double up[4] = {0, 0, 0, 0};
-    constexpr int kOutX = pair::kPairs * NU * T, kOutJ = kOutX + pair::kPairs * 3 * W;
-    volatile pair::lds_double *uo = stg + pl * NU * T, *xo = stg + kOutX + pl * 3 * W;
+    constexpr int kOutX = pair::kPairs * SU, kOutJ = kOutX + pair::kPairs * SX;
+    volatile pair::lds_double *uo = stg + pl * SU, *xo = stg + kOutX + pl * SX;
     const bool st_u = !s.odd, st_x = s.odd;
     if (st_x) {
 #pragma unroll
@@ -384,9 +385,9 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
     }
     if (st_x) ((volatile pair::lds_double *)stg)[kOutJ + pl] = bad ? nan : J;
     __builtin_amdgcn_wave_barrier();
-    pair::stage_out<pair::kPairs * NU * T>(a.u_out + b0 * NU * T, nb * NU * T, stg, lane);
-    pair::stage_out<pair::kPairs * 3 * W>(a.x_out + b0 * 3 * W, nb * 3 * W, stg + kOutX, lane);
-    pair::stage_out<pair::kPairs>(a.obj_out + b0, nb, stg + kOutJ, lane);
+    pair::stage_out<pair::kPairs * NU * T, NU * T>(a.u_out + b0 * NU * T, nb * NU * T, stg, lane);
+    pair::stage_out<pair::kPairs * 3 * W, 3 * W>(a.x_out + b0 * 3 * W, nb * 3 * W, stg + kOutX, lane);
+    if (lane < nb) a.obj_out[b0 + lane] = ((const volatile pair::lds_double *)stg)[kOutJ + lane];
     if (live && !s.odd) {
         a.status_out[b] = status;
         if (a.iters_out) a.iters_out[b] = iters;

@@ -1,0 +1,83 @@
+"""Multi-GPU layout of a batch of MPC instances: one process per GPU, each owning a
+contiguous slice of the instances.  Instances never interact, so the data path has no
+collective; torch.distributed is used only to agree on timing (max over ranks) and, when
+a caller wants the whole result on one rank, for a plain gather.
+
+Nothing here touches a GPU API, so the same code runs under the `gloo` backend on CPU."""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+
+def partition(total: int, world: int) -> List[Tuple[int, int]]:
+    """Balanced contiguous [start, stop) ranges: the first `total % world` ranks get one more."""
+    if world < 1 or total < 0:
+        raise ValueError("partition needs world >= 1 and total >= 0")
+    base, extra = divmod(total, world)
+    out, start = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+def my_slice(total: int, rank: int, world: int) -> slice:
+    lo, hi = partition(total, world)[rank]
+    return slice(lo, hi)
+
+
+def shard_arrays(arrays: Dict[str, np.ndarray], rank: int, world: int) -> Dict[str, np.ndarray]:
+    """This rank's rows of every per-instance array (strong scaling: the batch is split)."""
+    sizes = {a.shape[0] for a in arrays.values()}
+    if len(sizes) != 1:
+        raise ValueError("all arrays must have the same leading (instance) dimension")
+    sl = my_slice(sizes.pop(), rank, world)
+    return {k: a[sl] for k, a in arrays.items()}
+
+
+def rank_seed(base: int, rank: int) -> int:
+    """Seed of a rank's own synthetic shard (weak scaling: every rank builds a full batch)."""
+    return base + 1 + 1000 * rank
+
+
+def max_over_ranks(value: float, dist=None, device=None) -> float:
+    """The slowest rank's time: what a whole-job throughput must be computed from."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, dist=None, device=None) -> float:
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_rows(local: np.ndarray, total: int, dist=None) -> np.ndarray | None:
+    """Rows of every rank back in instance order on rank 0 (None elsewhere).  Not part of
+    the hot path: a caller that keeps results on the GPUs never needs it."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parts: Sequence = [None] * world
+    dist.gather_object(local, parts if rank == 0 else None, dst=0)
+    if rank != 0:
+        return None
+    out = np.concatenate(list(parts), axis=0)
+    if out.shape[0] != total:
+        raise RuntimeError(f"gathered {out.shape[0]} rows, expected {total}")
+    return out
+
+
+def whole_job_rate(units_per_rank: int, world: int, steps: int, elapsed_max: float) -> float:
+    """Aggregate units/s over all ranks for `steps` passes timed at the slowest rank."""
+    return world * units_per_rank * steps / elapsed_max
