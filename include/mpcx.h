@@ -134,6 +134,22 @@ int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int
                            const double *cyaw, const int32_t *clen, int64_t n_courses, int64_t Lmax,
                            int32_t *ind_out, double *mind_out, double *xref_out, void *stream);
 
+/* What do_simulation does between two solves (mpc_diff_drive.py:363-383, mpc_dsr.py:548-571,
+ * mpc_sim.py:224-247): update_state with the first control column when the solve succeeded
+ * (mpc_diff_drive.py:92-100; mpc_dsr.py:112-121 after transfrom_gbm_command, :123-150),
+ * warm-start carry (has_prev = 1) or cold start after a failure (has_prev = 0), check_goal
+ * (mpc_diff_drive.py:299-316) against the last point of the instance's course.
+ *   u [B][NU][T], status [B]: outputs of mpcx_solve_batch;  target_ind [B]: ind_out of
+ *   mpcx_nearest_ref_batch for this tick;  state [B][4] = x, y, yaw, vx (updated in place);
+ *   twist [B][2] = vy, w of the applied command (or NULL);  done [B]: 0 running, 1 goal
+ *   reached, 2 reference window lost (frozen from then on);  ticks [B]: ticks executed;
+ *   log_out [B][4] or NULL: the state after this tick. */
+int mpcx_advance_batch(const mpcx_variant *v, int64_t B, double goal_dis, double stop_speed, const double *u,
+                       const int32_t *status, const int32_t *target_ind, const int32_t *course_id,
+                       const double *cx, const double *cy, const int32_t *clen, int64_t n_courses, int64_t Lmax,
+                       double *state, double *twist, uint8_t *has_prev, uint8_t *done, int32_t *ticks,
+                       double *log_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

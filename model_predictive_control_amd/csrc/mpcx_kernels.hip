@@ -463,6 +463,80 @@ __global__ __launch_bounds__(256) void k_linearize(mpcx_variant v, int64_t B, co
 // Distances are dx*dx + dy*dy in float64 with no fused multiply-add: the index has to be
 // bit-exact.
 // ------------------------------------------------------------------------------------
+// closed loop: what do_simulation does between two solves
+// ------------------------------------------------------------------------------------
+// One lane per instance.  update_state with the first control column (mpc_diff_drive.py:92-100;
+// mpc_dsr.py:112-121 after transfrom_gbm_command, :123-150), only when the solve succeeded
+// (`if ov is not None`, mpc_diff_drive.py:368-370); the next solve is warm-started from this
+// solution, or cold-started after a failure (the reference's ov stays None); check_goal
+// (mpc_diff_drive.py:299-316) against the last point of the instance's course.  Instances
+// that reached the goal (done = 1) or lost their reference window (done = 2, where the
+// reference raises) are frozen.
+template <int MODEL>
+__global__ __launch_bounds__(256) void k_advance(mpcx_variant v, int64_t B, double goal_dis, double stop_speed,
+                                                 const double *__restrict__ u, const int32_t *__restrict__ status,
+                                                 const int32_t *__restrict__ target_ind,
+                                                 const int32_t *__restrict__ course_id,
+                                                 const double *__restrict__ cx, const double *__restrict__ cy,
+                                                 const int32_t *__restrict__ clen, int64_t Lmax,
+                                                 double *__restrict__ state, double *__restrict__ twist,
+                                                 uint8_t *__restrict__ has_prev, uint8_t *__restrict__ done,
+                                                 int32_t *__restrict__ ticks, double *__restrict__ log_out)
+{
+    constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double x = state[4 * b], y = state[4 * b + 1], yaw = state[4 * b + 2], vx = state[4 * b + 3];
+    if (!done[b]) {
+        const int T = v.T;
+        const bool solved = status[b] <= MPCX_ST_INACCURATE;
+        if (solved) {
+            double uc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < NU; ++r) uc[r] = u[(b * NU + r) * T];
+            double s, c;
+            sincos_fast(yaw, s, c);
+            const double dt = v.dt;
+            if (MODEL == MPCX_MODEL_DIFF_DRIVE) {
+                x = x + uc[0] * c * dt;
+                y = y + uc[0] * s * dt;
+                yaw = yaw + uc[1] * dt;
+                vx = uc[0];
+                if (twist) { twist[2 * b] = 0.0; twist[2 * b + 1] = uc[1]; }
+            } else {
+                double sf, cf, sr, cr;
+                sincos_fast(uc[1], sf, cf);
+                sincos_fast(uc[3], sr, cr);
+                const double v1x = cf * uc[0], v1y = sf * uc[0], v2x = cr * uc[2], v2y = sr * uc[2];
+                const double tx = 0.5 * (v1x + v2x), ty = 0.5 * (v1y + v2y), tw = (v1y - v2y) / v.wb;
+                x = x + tx * c * dt - ty * s * dt;
+                y = y + tx * s * dt + ty * c * dt;
+                yaw = yaw + tw * dt;
+                vx = tx;
+                if (twist) { twist[2 * b] = ty; twist[2 * b + 1] = tw; }
+            }
+            state[4 * b] = x; state[4 * b + 1] = y; state[4 * b + 2] = yaw; state[4 * b + 3] = vx;
+        }
+        has_prev[b] = solved ? 1 : 0;
+        ticks[b] += 1;
+        const int64_t course = course_id ? course_id[b] : 0;
+        const int len = clen[course];
+        const int tind = target_ind[b];
+        if (tind < 0) {
+            done[b] = 2;
+        } else {
+            const double dx = x - cx[course * Lmax + len - 1], dy = y - cy[course * Lmax + len - 1];
+            bool isgoal = hypot(dx, dy) <= goal_dis;
+            if (abs(tind - len) >= 5) isgoal = false;
+            if (isgoal && fabs(vx) <= stop_speed) done[b] = 1;
+        }
+    }
+    if (log_out) {
+        log_out[4 * b] = x; log_out[4 * b + 1] = y; log_out[4 * b + 2] = yaw; log_out[4 * b + 3] = vx;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 constexpr int kGroup = 16;
 
 __global__ __launch_bounds__(256) void k_nearest_ref(int mode, int T, double dt, double param, int n_search,
@@ -500,6 +574,9 @@ __global__ __launch_bounds__(256) void k_nearest_ref(int mode, int T, double dt,
         if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
     const bool empty = pind < 0 || hi <= lo;
+    // every distance NaN (a non-finite position): no comparison ever held, and Python's min()
+    // and list.index() then settle on the first element of the window
+    if (!empty && bi == 0x7fffffff) { bi = lo; best = __builtin_nan(""); }
     const int W = T + 1;
     if (empty) {
         if (live && k == 0) {
@@ -852,6 +929,31 @@ int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int
                        state, course_id, pind, cx, cy, cyaw, clen, Lmax, ind_out, mind_out, xref_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "k_nearest_ref launch");
+}
+
+
+int mpcx_advance_batch(const mpcx_variant *v, int64_t B, double goal_dis, double stop_speed, const double *u,
+                       const int32_t *status, const int32_t *target_ind, const int32_t *course_id,
+                       const double *cx, const double *cy, const int32_t *clen, int64_t n_courses, int64_t Lmax,
+                       double *state, double *twist, uint8_t *has_prev, uint8_t *done, int32_t *ticks,
+                       double *log_out, void *stream)
+{
+    if (int rc = check_variant(v)) return rc;
+    if (B < 0 || n_courses < 1 || Lmax < 1) return fail(MPCX_E_ARG, "bad sizes");
+    if (B == 0) return 0;
+    if (!u || !status || !target_ind || !cx || !cy || !clen || !state || !has_prev || !done || !ticks)
+        return fail(MPCX_E_ARG, "NULL buffer");
+    const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    if (v->model == MPCX_MODEL_DIFF_DRIVE)
+        hipLaunchKernelGGL(k_advance<MPCX_MODEL_DIFF_DRIVE>, grid, block, 0, (hipStream_t)stream, *v, B, goal_dis,
+                           stop_speed, u, status, target_ind, course_id, cx, cy, clen, Lmax, state, twist, has_prev,
+                           done, ticks, log_out);
+    else
+        hipLaunchKernelGGL(k_advance<MPCX_MODEL_DSR>, grid, block, 0, (hipStream_t)stream, *v, B, goal_dis,
+                           stop_speed, u, status, target_ind, course_id, cx, cy, clen, Lmax, state, twist, has_prev,
+                           done, ticks, log_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "k_advance launch");
 }
 
 }  // extern "C"

@@ -2,6 +2,8 @@
 current HIP stream; every computation happens in libmpcx.so."""
 from __future__ import annotations
 
+import math
+
 import ctypes as C
 from typing import Dict, Optional
 
@@ -154,3 +156,89 @@ def nearest_ref_batch(mode: int, T: int, dt: float, param: float, state, course_
                                           _ptr(table.cyaw), _ptr(table.clen), table.K, table.Lmax,
                                           _ptr(ind), _ptr(mind), _ptr(xref), _stream()))
     return ind, mind, xref
+
+
+class ClosedLoop:
+    """Device-resident closed loop over a batch of vehicles: per tick, reference window
+    (calc_ref_trajectory2) -> iterative_linear_mpc_control -> update_state, warm-start carry,
+    check_goal, with no host round trip (do_simulation of mpc_diff_drive.py:319-383,
+    mpc_dsr.py:504-571, MPC.doSimulation of mpc_sim.py:201-247, minus the plotting).
+
+    state [B,4] = x, y, yaw, vx;  course_id [B] indexes `table`.  After `run(n)`:
+    `state`, `twist` (vy, w), `done` (0 running / 1 goal / 2 window lost), `ticks`,
+    `target_ind`, the last solve in `out`, and `log` [n_ticks+1, B, 4] if asked for."""
+
+    def __init__(self, v: CVariant, table: CourseTable, state, course_id=None, goal_dis: float = 1.5,
+                 stop_speed: float = 0.5 / 3.6, n_search_ind: int = 2, n_search: int = 10, log_ticks: int = 0,
+                 pind0=None):
+        self.lib = _lib.load()
+        self.v, self.table = v, table
+        self.state = _dev(state).clone()
+        B = self.B = self.state.shape[0]
+        if tuple(self.state.shape) != (B, 4):
+            raise ValueError("state must be [B,4] = x, y, yaw, vx")
+        dev = self.state.device
+        self.course_id = None if course_id is None else _dev(course_id, torch.int32)
+        self.goal_dis, self.stop_speed = float(goal_dis), float(stop_speed)
+        self.n_search_ind, self.n_search = int(n_search_ind), int(n_search)
+        self.twist = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+        self.has_prev = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.done = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.ticks = torch.zeros(B, dtype=torch.int32, device=dev)
+        # the first nearest-index search starts at the course start, as the reference's does,
+        # unless the caller knows where along its course each vehicle is
+        self.target_ind = torch.zeros(B, dtype=torch.int32, device=dev) if pind0 is None else _dev(pind0, torch.int32).clone()
+        self.xref = torch.empty((B, 3, v.T + 1), dtype=torch.float64, device=dev)
+        self.x0 = torch.empty((B, 3), dtype=torch.float64, device=dev)
+        # the solve reads the previous optimum while it writes the new one: two buffers
+        self.out = _outputs(B, v.nu, v.T, dev)
+        self.uprev = torch.zeros((B, v.nu, v.T), dtype=torch.float64, device=dev)
+        self.log = torch.empty((log_ticks + 1, B, 4), dtype=torch.float64, device=dev) if log_ticks else None
+        self.n_done_ticks = 0
+        self._initial_alignment()
+
+    def _initial_alignment(self):
+        """Initial yaw compensation against the course's first yaw and the first nearest index
+        searched from the course start (mpc_diff_drive.py:336-350)."""
+        cid = self.course_id.long() if self.course_id is not None else torch.zeros(self.B, dtype=torch.long, device=self.state.device)
+        d = self.state[:, 2] - self.table.cyaw[cid, 0]
+        two_pi = 2.0 * math.pi
+        self.state[:, 2] = torch.where(d >= math.pi, self.state[:, 2] - two_pi,
+                                       torch.where(d <= -math.pi, self.state[:, 2] + two_pi, self.state[:, 2]))
+        t = self.table
+        _lib.check(self.lib.mpcx_nearest_ref_batch(1, self.v.T, self.v.dt, float(self.n_search_ind), self.n_search, 1,
+                                                   self.B, _ptr(self.state), _ptr(self.course_id), _ptr(self.target_ind),
+                                                   _ptr(t.cx), _ptr(t.cy), _ptr(t.cyaw), _ptr(t.clen), t.K, t.Lmax,
+                                                   _ptr(self.target_ind), None, None, _stream()))
+        if self.log is not None:
+            self.log[0].copy_(self.state)
+
+    def tick(self):
+        t, v, lib, st = self.table, self.v, self.lib, _stream()
+        _lib.check(lib.mpcx_nearest_ref_batch(1, v.T, v.dt, float(self.n_search_ind), self.n_search, 1, self.B,
+                                              _ptr(self.state), _ptr(self.course_id), _ptr(self.target_ind),
+                                              _ptr(t.cx), _ptr(t.cy), _ptr(t.cyaw), _ptr(t.clen), t.K, t.Lmax,
+                                              _ptr(self.target_ind), None, _ptr(self.xref), st))
+        o = self.out
+        self.x0.copy_(self.state[:, :3])   # x0 = [state.x, state.y, state.yaw]
+        _lib.check(lib.mpcx_solve_batch(C.byref(v), self.B, _ptr(self.x0), _ptr(self.xref), _ptr(self.uprev),
+                                        _ptr(self.has_prev), _ptr(o["u"]), _ptr(o["x"]), _ptr(o["obj"]),
+                                        _ptr(o["status"]), _ptr(o["iters"]), st))
+        k = self.n_done_ticks + 1
+        log = self.log[k] if self.log is not None and k < self.log.shape[0] else None
+        _lib.check(lib.mpcx_advance_batch(C.byref(v), self.B, self.goal_dis, self.stop_speed, _ptr(o["u"]),
+                                          _ptr(o["status"]), _ptr(self.target_ind), _ptr(self.course_id),
+                                          _ptr(t.cx), _ptr(t.cy), _ptr(t.clen), t.K, t.Lmax, _ptr(self.state),
+                                          _ptr(self.twist), _ptr(self.has_prev), _ptr(self.done), _ptr(self.ticks),
+                                          _ptr(log), st))
+        o["u"], self.uprev = self.uprev, o["u"]   # this optimum warm-starts the next tick
+        self.n_done_ticks = k
+
+    def run(self, n_ticks: int):
+        for _ in range(n_ticks):
+            self.tick()
+        return self
+
+    @property
+    def last_u(self):
+        return self.uprev

@@ -104,6 +104,20 @@ def test_nearest_empty_window_and_wide_search(eng, golden):
         _same_distance(mind.cpu().numpy(), wm)
 
 
+def test_nearest_with_a_non_finite_position(eng, golden):
+    """x = NaN makes every distance NaN; Python's min()/index() then return the first element
+    of the window, and so must the kernel (it must not index with an unset argmin)."""
+    tab = _course_table(eng, golden)
+    cx, cy, cyaw = tab.cx.cpu().numpy(), tab.cy.cpu().numpy(), tab.cyaw.cpu().numpy()
+    state = np.array([[np.nan, 0.0, 0.0, 0.1], [1.0, np.inf, 0.0, 0.1], [1.0, 2.0, 0.0, 0.1]])
+    cid, pind = np.zeros(3, np.int32), np.array([3, 0, 5], np.int32)
+    ind, mind, xr = eng.nearest_ref_batch(1, 5, 0.2, 2, state, cid, pind, tab)
+    wi, wm, wx = orc.nearest_ref_batch(1, 5, 0.2, 2, state, cid, pind, cx, cy, cyaw, tab.clen_host)
+    assert np.array_equal(ind.cpu().numpy(), wi) and wi[0] == 3 and wi[1] == 0
+    assert np.array_equal(xr.cpu().numpy(), wx)
+    assert np.isnan(mind.cpu().numpy()[0]) and np.isnan(wm[0])
+
+
 # ------------------------------------------------------------------------------- QP solve
 
 @pytest.mark.parametrize("name", T5_VARIANTS)
