@@ -213,14 +213,20 @@ class ClosedLoop:
         if self.log is not None:
             self.log[0].copy_(self.state)
 
+    def prepare(self):
+        """First third of a tick: the inputs of the next solve (`x0`, `xref`; `uprev` and
+        `has_prev` are already in place)."""
+        t, v = self.table, self.v
+        _lib.check(self.lib.mpcx_nearest_ref_batch(1, v.T, v.dt, float(self.n_search_ind), self.n_search, 1, self.B,
+                                                   _ptr(self.state), _ptr(self.course_id), _ptr(self.target_ind),
+                                                   _ptr(t.cx), _ptr(t.cy), _ptr(t.cyaw), _ptr(t.clen), t.K, t.Lmax,
+                                                   _ptr(self.target_ind), None, _ptr(self.xref), _stream()))
+        self.x0.copy_(self.state[:, :3])   # x0 = [state.x, state.y, state.yaw]
+
     def tick(self):
         t, v, lib, st = self.table, self.v, self.lib, _stream()
-        _lib.check(lib.mpcx_nearest_ref_batch(1, v.T, v.dt, float(self.n_search_ind), self.n_search, 1, self.B,
-                                              _ptr(self.state), _ptr(self.course_id), _ptr(self.target_ind),
-                                              _ptr(t.cx), _ptr(t.cy), _ptr(t.cyaw), _ptr(t.clen), t.K, t.Lmax,
-                                              _ptr(self.target_ind), None, _ptr(self.xref), st))
+        self.prepare()
         o = self.out
-        self.x0.copy_(self.state[:, :3])   # x0 = [state.x, state.y, state.yaw]
         _lib.check(lib.mpcx_solve_batch(C.byref(v), self.B, _ptr(self.x0), _ptr(self.xref), _ptr(self.uprev),
                                         _ptr(self.has_prev), _ptr(o["u"]), _ptr(o["x"]), _ptr(o["obj"]),
                                         _ptr(o["status"]), _ptr(o["iters"]), st))
