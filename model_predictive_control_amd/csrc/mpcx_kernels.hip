@@ -218,7 +218,8 @@ __global__ __launch_bounds__(kWave) void k_solve_reg(SolveArgs a)
 constexpr int kPairIpmIters = MPCX_PAIR_K;   // interior-point iterations before the active-set rounds
 constexpr int kPairRounds0 = 6;              // active-set rounds after them
 constexpr int kPairRounds1 = 4;              // ... and after a converged interior-point solve
-template <int MODEL>
+// CHAIN: the MPC.iterativeLMPC flavour (T chained QPs per call); otherwise exactly one QP.
+template <int MODEL, bool CHAIN>
 __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a)
 {
     // LDS: Hs = input staging (x0, controls, xbar), then H and g, then output staging;
@@ -297,10 +298,8 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
         lp.theta0 = 0.0;
     }
     MPCX_STAMP(9);
-    pair::assemble<MODEL>(s, v, lp, x0, xr);
-    MPCX_STAMP(1);
     {
-        FreeBounds fb;
+        FreeBounds fb;   // the first-stage window hangs on the incoming first column, in every pass
         free_bounds(v, u0, fb);
         if (!fb.feasible && !skip) { skip = true; status = MPCX_ST_INFEASIBLE; }
         s.b_ = s.odd ? fb.b[1] : fb.b[0];
@@ -308,38 +307,76 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
         s.lo0 = s.odd ? fb.lo0[1] : fb.lo0[0];
         s.hi0 = s.odd ? fb.hi0[1] : fb.hi0[0];
     }
-    // Attempt 0: a fixed, wave-uniform number of interior-point iterations, then active-set
-    // rounds that either certify the exact optimum or give up.  Attempt 1 (only for lanes
-    // attempt 0 left unsettled): interior point to convergence, then the same rounds; if
-    // those do not settle either, the converged interior-point iterate is the answer.
-    {
+    // MPC.iterativeLMPC solves T QPs per call, each linearised about column `pass` of the
+    // previous answer (mpc_sim.py:293-306); every other caller solves one.
+    const int chain = !CHAIN ? 1 : (v.chain < T ? v.chain : T);
+    const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
+    pair::LinRegs L;
+    bool inaccurate = false;
+    pair::prepare_lin<MODEL>(s, v, lp, CHAIN, L);
+#pragma unroll 1
+    for (int pass = 0; pass < chain; ++pass) {
+        if (CHAIN && pass > 0) {
+            // column `pass` of the linearisation controls <- the previous answer
+            double wp0 = 0.0, wp1 = 0.0;
+#pragma unroll
+            for (int t = 1; t < T; ++t) {
+                if (t == pass) {
+                    wp0 = s.odd ? s.wo[t] : s.ws[t];
+                    wp1 = s.odd ? s.ws[t] : s.wo[t];
+                }
+            }
+            double un[4];
+            if (v.eq_mode == MPCX_EQ_NONE) { un[0] = wp0; un[1] = wp1; un[2] = 0.0; un[3] = 0.0; }
+            else if (v.eq_mode == MPCX_EQ_FIXED_STEER) { un[0] = wp0; un[1] = v.steer_fixed; un[2] = wp1; un[3] = v.steer_fixed; }
+            else { un[0] = wp0; un[1] = wp1; un[2] = wp0; un[3] = sg * wp1; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (L.tj[j] == pass) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) L.u[j][r] = un[r];
+                }
+            }
+        }
+        pair::stage_eval<MODEL>(s, v, L, CHAIN);
+        if (pass == 0) MPCX_STAMP(10);
+        pair::condense(s, v, x0, xr);
+        if (pass == 0) MPCX_STAMP(1);
+        // Attempt 0: a fixed, wave-uniform number of interior-point iterations, then active-set
+        // rounds that either certify the exact optimum or give up.  Attempt 1 (only for lanes
+        // attempt 0 left unsettled): interior point to convergence, then the same rounds; if
+        // those do not settle either, the converged interior-point iterate is the answer.
         bool need = !skip;
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; ++attempt) {
             int st = MPCX_ST_OK, it = 0;
             pair::ipm(s, attempt == 0 ? (a.max_iter < kPairIpmIters ? a.max_iter : kPairIpmIters) : a.max_iter, attempt == 0, !need, st, it);
-            MPCX_STAMP(2 + 2 * attempt);
+            if (pass == 0) MPCX_STAMP(2 + 2 * attempt);
             if (need) { iters += it; status = st; }
-            const bool failed = need && attempt == 1 && st == MPCX_ST_FAILED;
+            // the rounds run even after an interior-point solve that stalled short of its
+            // tolerances: they certify their own answer, and a stalled iterate usually has the set
 #ifdef MPCX_STAMPS
             int rounds = 0;
-            const bool settled = pair::pdas(s, !need || failed, attempt == 0 ? kPairRounds0 : kPairRounds1, &rounds);
-            if (attempt == 0 && threadIdx.x == 0 && blockIdx.x < kStampWaves) g_stamps[blockIdx.x * kStampSlots + 7] = rounds;
+            const bool settled = pair::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1, &rounds);
+            if (pass == 0 && attempt == 0 && threadIdx.x == 0 && blockIdx.x < kStampWaves) g_stamps[blockIdx.x * kStampSlots + 7] = rounds;
 #else
-            const bool settled = pair::pdas(s, !need || failed, attempt == 0 ? kPairRounds0 : kPairRounds1);
+            const bool settled = pair::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1);
 #endif
-            MPCX_STAMP(3 + 2 * attempt);
+            if (pass == 0) MPCX_STAMP(3 + 2 * attempt);
             if (need && settled) status = MPCX_ST_OK;
             need = need && !settled;
             if (!__any(need)) break;
         }
+        if (!skip && status == MPCX_ST_FAILED) skip = true;   // the reference's chain dies with its first failed solve
+        if (CHAIN && !skip && status == MPCX_ST_INACCURATE) inaccurate = true;
     }
+    // an inaccurate link makes the whole chain's answer inaccurate, whatever the last solve says
+    if (CHAIN && inaccurate && status == MPCX_ST_OK) status = MPCX_ST_INACCURATE;
 
     // epilogue (both lanes evaluate it; the even lane stages the controls, the odd lane the
     // states and the objective; the wave then writes its 32 records as contiguous blocks)
     const bool bad = status == MPCX_ST_NONFINITE || status == MPCX_ST_INFEASIBLE;
     const double nan = __builtin_nan("");
-    const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
     double J = 0.0, qg = 1.0;
     double x[3] = {x0[0], x0[1], x0[2]};
     double up[4] = {0, 0, 0, 0};
@@ -696,10 +733,15 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
     if (uses_registers(v)) {
         const dim3 grid((unsigned)((a.B + kWave - 1) / kWave)), block(kWave);
         const bool chained = !a.linear_mode && v->chain > 1;
-        if (!chained && !g_force_single_lane) {
+        if (!g_force_single_lane) {
             const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
-            if (v->model == MPCX_MODEL_DIFF_DRIVE) hipLaunchKernelGGL((k_solve_pair<0>), pgrid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_solve_pair<1>), pgrid, block, 0, st, a);
+            if (v->model == MPCX_MODEL_DIFF_DRIVE) {
+                if (chained) hipLaunchKernelGGL((k_solve_pair<0, true>), pgrid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_solve_pair<0, false>), pgrid, block, 0, st, a);
+            } else {
+                if (chained) hipLaunchKernelGGL((k_solve_pair<1, true>), pgrid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_solve_pair<1, false>), pgrid, block, 0, st, a);
+            }
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hip_fail(e, "k_solve_pair launch");
             return 0;

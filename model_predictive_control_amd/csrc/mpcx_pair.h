@@ -614,50 +614,78 @@ __device__ __forceinline__ void load_dyn(const State &s, int t, Dyn &d)
     }
 }
 
-// Stage dynamics of the instance into LDS, the five stages split between the two lanes
-// (even lane: stages 0, 2, 4; odd lane: 1, 3 and 4 again, writing the same numbers).  The
-// yaw of the linearisation points is rolled from the yaw rates exactly as predict_motion
-// does (mpc_diff_drive.py:126-139), the rates of the partner's stages arriving by DPP.
+// Linearisation point of the lane's own stages (even lane: stages 0, 2, 4; odd lane: 1, 3 and
+// 4 again), kept in registers over the solves of one call.
+struct LinRegs {
+    double u[3][4];    // controls at the linearisation point
+    double th[3];      // yaw at the linearisation point
+    SteerTerms k[3];   // sines / cosines of the steer angles of u
+    int tj[3];         // which stage each slot is
+};
+
+// Controls and yaw of the lane's stages from the staged inputs.  The yaw is rolled from the
+// yaw rates exactly as predict_motion does (mpc_diff_drive.py:126-139), the rates of the
+// partner's stages arriving by DPP.  With `chained` (MPC.iterativeLMPC, mpc_sim.py:292-299)
+// the yaw still follows the incoming controls, but the controls of the linearisation point
+// start as column 0 of them with the rest zero.
 template <int MODEL>
-__device__ __forceinline__ void stage_split(State &s, const mpcx_variant &v, const Lin &lp)
+__device__ __forceinline__ void prepare_lin(const State &s, const mpcx_variant &v, const Lin &lp, bool chained,
+                                            LinRegs &L)
 {
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     const bool odd = s.odd;
-    double u[3][4], th[3];
-    SteerTerms k[3];
-    int tj[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         int t = 2 * j + (odd ? 1 : 0);
         t = t < TT ? t : TT - 1;
-        tj[j] = t;
+        L.tj[j] = t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u[j][r] = 0.0;
+        for (int r = 0; r < 4; ++r) L.u[j][r] = 0.0;
 #pragma unroll
-        for (int r = 0; r < NU; ++r) u[j][r] = lp.control(r, t);
-        steer_terms<MODEL>(v, u[j], k[j]);
+        for (int r = 0; r < NU; ++r) L.u[j][r] = lp.control(r, t);
+        steer_terms<MODEL>(v, L.u[j], L.k[j]);
     }
     if (lp.has_yaw) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) th[j] = lp.yaw[tj[j]];
+        for (int j = 0; j < 3; ++j) L.th[j] = lp.yaw[L.tj[j]];
     } else {
-        const double w0 = from_even(k[0].omega), w1 = from_odd(k[0].omega);
-        const double w2 = from_even(k[1].omega), w3 = from_odd(k[1].omega);
+        const double w0 = from_even(L.k[0].omega), w1 = from_odd(L.k[0].omega);
+        const double w2 = from_even(L.k[1].omega), w3 = from_odd(L.k[1].omega);
         const double t0 = lp.theta0;
         const double t1 = t0 + w0 * v.dt;
         const double t2 = t1 + w1 * v.dt;
         const double t3 = t2 + w2 * v.dt;
         const double t4 = t3 + w3 * v.dt;
-        th[0] = odd ? t1 : t0;
-        th[1] = odd ? t3 : t2;
-        th[2] = t4;
+        L.th[0] = odd ? t1 : t0;
+        L.th[1] = odd ? t3 : t2;
+        L.th[2] = t4;
+    }
+    if (chained) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (L.tj[j] > 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) L.u[j][r] = 0.0;
+            }
+        }
+    }
+}
+
+// Stage dynamics of the lane's stages into LDS (both lanes then read all five).  `fresh`:
+// the controls changed since the steer terms were last evaluated.
+template <int MODEL>
+__device__ __forceinline__ void stage_eval(State &s, const mpcx_variant &v, LinRegs &L, bool fresh)
+{
+    if (fresh) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) steer_terms<MODEL>(v, L.u[j], L.k[j]);
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         double a02, a12, Bm[3][4], C[3], bt[3][2], ct[3];
-        linearize_at<MODEL>(v, th[j], u[j], k[j], a02, a12, Bm, C);
+        linearize_at<MODEL>(v, L.th[j], L.u[j], L.k[j], a02, a12, Bm, C);
         reduce_controls(v, Bm, C, bt, ct);
-        volatile lds_double *p = (volatile lds_double *)s.dyn + tj[j] * kDynPerStage * kPairs;
+        volatile lds_double *p = (volatile lds_double *)s.dyn + L.tj[j] * kDynPerStage * kPairs;
         p[0] = a02;
         p[kPairs] = a12;
 #pragma unroll
@@ -671,10 +699,9 @@ __device__ __forceinline__ void stage_split(State &s, const mpcx_variant &v, con
 }
 
 // Condensed Hessian rows and gradient entries of the lane's channel, straight into LDS.
-// The stage dynamics come from LDS (stage_split); each lane accumulates its own rows of H.
-template <int MODEL>
-__device__ __forceinline__ void assemble(State &s, const mpcx_variant &v, const Lin &lp,
-                                         const double (&x0)[3], const volatile lds_double *xref)
+// The stage dynamics come from LDS (stage_eval); each lane accumulates its own rows of H.
+__device__ __forceinline__ void condense(State &s, const mpcx_variant &v, const double (&x0)[3],
+                                         const volatile lds_double *xref)
 {
     constexpr int W = TT + 1;
     const bool odd = s.odd;
@@ -705,10 +732,6 @@ __device__ __forceinline__ void assemble(State &s, const mpcx_variant &v, const 
         HSa[bi(t, t)] = d;
         if (t > 0) HSa[bi(t, t - 1)] = -2.0 * rdc;
     }
-    stage_split<MODEL>(s, v, lp);
-#ifdef MPCX_STAMP
-    MPCX_STAMP(10);
-#endif
     double p[3] = {x0[0], x0[1], x0[2]};
     double qg = 1.0;
 #pragma unroll

@@ -728,18 +728,20 @@ static int iterate_one(const orc_variant *v, const double *xref, const double *x
     if (v->chain <= 1)
         return solve_one(v, xref, xbar, x0, uin, u_out, x_out, obj, iters, kkt, mem);
     memset(uref, 0, sizeof(double) * NU * T);
-    int st = ORC_ST_OK, tot = 0;
+    int st = ORC_ST_OK, tot = 0, inaccurate = 0;
     const double *cur = uin;
     for (int i = 0; i < v->chain && i < T; ++i) {
         for (int r = 0; r < NU; ++r) uref[r * T + i] = cur[r * T + i];
         int it = 0;
         st = solve_one(v, xref, xbar, x0, uref, u_out, x_out, obj, &it, kkt, mem);
         tot += it;
-        if (st == ORC_ST_INFEASIBLE || st == ORC_ST_NONFINITE) break;
+        if (st != ORC_ST_OK && st != ORC_ST_INACCURATE) break;   /* the reference raises at ovf[i] on the next pass */
+        if (st == ORC_ST_INACCURATE) inaccurate = 1;
         cur = u_out;
     }
     *iters = tot;
-    return st;
+    /* an inaccurate link makes the whole chain's answer inaccurate, whatever the last solve says */
+    return (st == ORC_ST_OK && inaccurate) ? ORC_ST_INACCURATE : st;
 }
 
 /* ---------------------------------------------------------------- batched entry points */

@@ -18,7 +18,7 @@ def run(name, B, T=None, warm=True):
     torch.cuda.synchronize()
     def cmp(tag, out, ref):
         st = out["status"].cpu().numpy(); u = out["u"].cpu().numpy(); x = out["x"].cpu().numpy(); ob = out["obj"].cpu().numpy()
-        ok = (ref["status"] <= 1) & (st <= 1)
+        ok = (ref["status"] == 0) & (st <= 1)   # an oracle solve that calls itself inaccurate is no yardstick
         print(f"{name} T={v.T} {tag}: status gpu {np.bincount(st, minlength=5)} oracle {np.bincount(ref['status'], minlength=5)}"
               f" du {np.abs(u - ref['u'])[ok].max():.3e} dx {np.abs(x - ref['x'])[ok].max():.3e}"
               f" dobj {(np.abs(ob - ref['obj']) / np.maximum(1, np.abs(ref['obj'])))[ok].max():.3e}"

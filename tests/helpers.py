@@ -45,7 +45,8 @@ def compare(out, ref, u_tol=U_TIGHT, obj_tol=OBJ_TIGHT, x_tol=U_TIGHT):
     bad = ~good_ref
     assert np.array_equal(st[bad], ref["status"][bad])
     assert np.isnan(u[bad]).all() and np.isnan(obj[bad]).all()
-    g = good_ref
+    # where the oracle itself reports an inaccurate solve it is no yardstick for 1e-4
+    g = good_ref & (ref["status"] == 0)
     du = np.abs(u[g] - ref["u"][g]).max() if g.any() else 0.0
     dx = np.abs(x[g] - ref["x"][g]).max() if g.any() else 0.0
     dobj = (np.abs(obj[g] - ref["obj"][g]) / np.maximum(1.0, np.abs(ref["obj"][g]))).max() if g.any() else 0.0
