@@ -150,6 +150,17 @@ int mpcx_advance_batch(const mpcx_variant *v, int64_t B, double goal_dis, double
                        double *state, double *twist, uint8_t *has_prev, uint8_t *done, int32_t *ticks,
                        double *log_out, void *stream);
 
+/* calc_spline_course (cubic_spline_planner.py:311-323: CubicSpline2D :174-308 over two
+ * CubicSpline1D :12-171) for K courses at once, optionally followed by smooth_yaw
+ * (mpc_diff_drive.py:404-417): the producer of the course tables mpcx_nearest_ref_batch reads.
+ *   wx, wy [K][n_way_max] waypoints, nway [K] of them valid (2..64);
+ *   cx, cy, cyaw [K][Lmax] and ck [K][Lmax] (curvature, or NULL): samples at s = 0, ds, ...
+ *   below the total chord length;  clen [K] their number, -1 for a course that does not fit
+ *   Lmax or has repeated / non-finite waypoints (where the reference divides by zero). */
+int mpcx_build_courses_batch(int64_t K, int32_t n_way_max, const double *wx, const double *wy, const int32_t *nway,
+                             double ds, int64_t Lmax, int32_t smooth, double *cx, double *cy, double *cyaw,
+                             double *ck, int32_t *clen, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

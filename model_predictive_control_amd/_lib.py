@@ -50,6 +50,8 @@ SIGNATURES = {
     "mpcx_nearest_ref_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                          C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, C.c_int64, C.c_int64,
                                          _PD, _PD, _PD, _PD]),
+    "mpcx_build_courses_batch": (C.c_int, [C.c_int64, C.c_int32, _PD, _PD, _PD, C.c_double, C.c_int64, C.c_int32,
+                                           _PD, _PD, _PD, _PD, _PD, _PD]),
     "mpcx_advance_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, C.c_double, C.c_double, _PD, _PD, _PD, _PD,
                                      _PD, _PD, _PD, C.c_int64, C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
 }

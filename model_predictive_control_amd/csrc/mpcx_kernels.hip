@@ -500,6 +500,130 @@ __global__ __launch_bounds__(256) void k_linearize(mpcx_variant v, int64_t B, co
 // Distances are dx*dx + dy*dy in float64 with no fused multiply-add: the index has to be
 // bit-exact.
 // ------------------------------------------------------------------------------------
+// course builder: calc_spline_course + smooth_yaw, one 64-lane block per course
+// ------------------------------------------------------------------------------------
+constexpr int kMaxWaypoints = 64;
+
+// Natural cubic spline coefficients through (s_i, a_i), i < n (cubic_spline_planner.py:38-66,
+// 146-171): the reference solves the tridiagonal system densely; here it is eliminated
+// directly.  c[0] = c[n-1] = 0.
+__device__ inline void spline_coefficients(int n, const double *sk, const double *a, double *b, double *c, double *d,
+                                           double *dp, double *rp)
+{
+    for (int i = 0; i < n; ++i) c[i] = 0.0;
+    const int m = n - 2;
+    if (m > 0) {
+        for (int i = 0; i < m; ++i) {
+            const double h0 = sk[i + 1] - sk[i], h1 = sk[i + 2] - sk[i + 1];
+            dp[i] = 2.0 * (h0 + h1);
+            rp[i] = 3.0 * ((a[i + 2] - a[i + 1]) / h1 - (a[i + 1] - a[i]) / h0);
+        }
+        for (int i = 1; i < m; ++i) {
+            const double off = sk[i + 1] - sk[i];   // sub- and super-diagonal entry between rows i-1 and i
+            const double f = off / dp[i - 1];
+            dp[i] -= f * off;
+            rp[i] -= f * rp[i - 1];
+        }
+        c[m] = rp[m - 1] / dp[m - 1];
+        for (int i = m - 2; i >= 0; --i) c[i + 1] = (rp[i] - (sk[i + 2] - sk[i + 1]) * c[i + 2]) / dp[i];
+    }
+    for (int i = 0; i + 1 < n; ++i) {
+        const double h = sk[i + 1] - sk[i];
+        d[i] = (c[i + 1] - c[i]) / (3.0 * h);
+        b[i] = (a[i + 1] - a[i]) / h - h / 3.0 * (2.0 * c[i] + c[i + 1]);
+    }
+}
+
+// wx, wy [K][Nmax] waypoints (nway[k] valid, >= 2); outputs cx, cy, cyaw, ck [K][Lmax] and
+// clen[k] = number of samples s = 0, ds, 2 ds, ... < total chord length
+// (cubic_spline_planner.py:311-323), or -1 when they do not fit Lmax or the input is bad.
+// With `smooth` the yaw column is unwrapped sequentially as smooth_yaw does
+// (mpc_diff_drive.py:404-417).
+__global__ __launch_bounds__(kWave) void k_build_courses(int64_t K, int Nmax, const double *__restrict__ wx,
+                                                         const double *__restrict__ wy,
+                                                         const int32_t *__restrict__ nway, double ds, int64_t Lmax,
+                                                         int smooth, double *__restrict__ cx, double *__restrict__ cy,
+                                                         double *__restrict__ cyaw, double *__restrict__ ck,
+                                                         int32_t *__restrict__ clen)
+{
+    __shared__ double sk[kMaxWaypoints], ax[kMaxWaypoints], ay[kMaxWaypoints];
+    __shared__ double bx[kMaxWaypoints], cxs[kMaxWaypoints], dx_[kMaxWaypoints];
+    __shared__ double by[kMaxWaypoints], cys[kMaxWaypoints], dy_[kMaxWaypoints];
+    __shared__ double w1[kMaxWaypoints], w2[kMaxWaypoints], w3[kMaxWaypoints], w4[kMaxWaypoints];
+    __shared__ int s_len;
+    const int64_t k = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n = nway[k];
+    const bool ok = n >= 2 && n <= Nmax && n <= kMaxWaypoints;
+    if (ok && lane < n) { ax[lane] = wx[k * Nmax + lane]; ay[lane] = wy[k * Nmax + lane]; }
+    __syncthreads();
+    if (lane == 0) {
+        int len = -1;
+        if (ok) {
+            sk[0] = 0.0;
+            bool good = true;
+            for (int i = 0; i + 1 < n; ++i) {   // cumulative chord length, summed in order like numpy.cumsum
+                const double h = hypot(ax[i + 1] - ax[i], ay[i + 1] - ay[i]);
+                sk[i + 1] = sk[i] + h;
+                good = good && h > 0.0 && finite_d(h);
+            }
+            if (good && ds > 0.0) {
+                const double cnt = ceil(sk[n - 1] / ds);   // len(numpy.arange(0, s_end, ds))
+                if (cnt >= 1.0 && cnt <= (double)Lmax) len = (int)cnt;
+            }
+        }
+        s_len = len;
+    }
+    __syncthreads();
+    const int len = s_len;
+    if (len < 0) {
+        if (lane == 0) clen[k] = -1;
+        return;
+    }
+    if (lane == 0) spline_coefficients(n, sk, ax, bx, cxs, dx_, w1, w2);
+    if (lane == 1) spline_coefficients(n, sk, ay, by, cys, dy_, w3, w4);
+    __syncthreads();
+    double *ox = cx + k * Lmax, *oy = cy + k * Lmax, *ow = cyaw + k * Lmax, *oc = ck ? ck + k * Lmax : nullptr;
+    for (int i = lane; i < len; i += kWave) {
+        const double sv = (double)i * ds;                      // numpy.arange: start + i * step
+        int lo = 0, hi = n;                                    // bisect.bisect(knots, sv) - 1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sv < sk[mid]) hi = mid; else lo = mid + 1;
+        }
+        int seg = lo - 1;
+        seg = seg < 0 ? 0 : (seg > n - 2 ? n - 2 : seg);
+        const double t = sv - sk[seg];
+        const double t2 = __dmul_rn(t, t), t3 = __dmul_rn(t2, t);
+        // a + b t + c t^2 + d t^3, summed left to right without contraction, as Python does
+        const double px = __dadd_rn(__dadd_rn(__dadd_rn(ax[seg], __dmul_rn(bx[seg], t)), __dmul_rn(cxs[seg], t2)), __dmul_rn(dx_[seg], t3));
+        const double py = __dadd_rn(__dadd_rn(__dadd_rn(ay[seg], __dmul_rn(by[seg], t)), __dmul_rn(cys[seg], t2)), __dmul_rn(dy_[seg], t3));
+        const double vx = __dadd_rn(__dadd_rn(bx[seg], __dmul_rn(__dmul_rn(2.0, cxs[seg]), t)), __dmul_rn(__dmul_rn(3.0, dx_[seg]), t2));
+        const double vy = __dadd_rn(__dadd_rn(by[seg], __dmul_rn(__dmul_rn(2.0, cys[seg]), t)), __dmul_rn(__dmul_rn(3.0, dy_[seg]), t2));
+        const double axx = __dadd_rn(__dmul_rn(2.0, cxs[seg]), __dmul_rn(__dmul_rn(6.0, dx_[seg]), t));
+        const double ayy = __dadd_rn(__dmul_rn(2.0, cys[seg]), __dmul_rn(__dmul_rn(6.0, dy_[seg]), t));
+        ox[i] = px;
+        oy[i] = py;
+        ow[i] = atan2(vy, vx);
+        if (oc) oc[i] = (ayy * vx - axx * vy) / pow(vx * vx + vy * vy, 1.5);
+    }
+    if (lane == 0) clen[k] = len;
+    if (!smooth) return;
+    __syncthreads();   // the block's own global writes are visible to it after the barrier
+    if (lane == 0) {
+        double prev = ow[0];
+        for (int i = 0; i + 1 < len; ++i) {
+            double cur = ow[i + 1];
+            double dyaw = cur - prev;
+            while (dyaw >= M_PI / 2.0) { cur -= M_PI * 2.0; dyaw = cur - prev; }
+            while (dyaw <= -M_PI / 2.0) { cur += M_PI * 2.0; dyaw = cur - prev; }
+            ow[i + 1] = cur;
+            prev = cur;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // closed loop: what do_simulation does between two solves
 // ------------------------------------------------------------------------------------
 // One lane per instance.  update_state with the first control column (mpc_diff_drive.py:92-100;
@@ -996,6 +1120,21 @@ int mpcx_advance_batch(const mpcx_variant *v, int64_t B, double goal_dis, double
                            done, ticks, log_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "k_advance launch");
+}
+
+
+int mpcx_build_courses_batch(int64_t K, int32_t n_way_max, const double *wx, const double *wy, const int32_t *nway,
+                             double ds, int64_t Lmax, int32_t smooth, double *cx, double *cy, double *cyaw,
+                             double *ck, int32_t *clen, void *stream)
+{
+    if (K < 0 || n_way_max < 2 || n_way_max > kMaxWaypoints) return fail(MPCX_E_ARG, "waypoints per course must be 2..%d", kMaxWaypoints);
+    if (!(ds > 0.0) || Lmax < 1) return fail(MPCX_E_ARG, "ds must be positive and Lmax >= 1");
+    if (K == 0) return 0;
+    if (!wx || !wy || !nway || !cx || !cy || !cyaw || !clen) return fail(MPCX_E_ARG, "NULL buffer");
+    hipLaunchKernelGGL(k_build_courses, dim3((unsigned)K), dim3(kWave), 0, (hipStream_t)stream, K, (int)n_way_max, wx, wy,
+                       nway, ds, Lmax, (int)smooth, cx, cy, cyaw, ck, clen);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "k_build_courses launch");
 }
 
 }  // extern "C"

@@ -135,6 +135,42 @@ class CourseTable:
         self.cx, self.cy, self.cyaw = _dev(tx), _dev(ty), _dev(tw)
         self.clen = _dev(ln, torch.int32)
         self.clen_host = ln
+        self.ck = None
+
+    @classmethod
+    def from_waypoints(cls, waypoints, ds: float = 0.1, smooth: bool = True, Lmax: Optional[int] = None):
+        """Builds the tables on the device from waypoint lists [(x_k, y_k), ...]:
+        cubic_spline_planner.calc_spline_course per course, then smooth_yaw
+        (mpc_diff_drive.py:404-417) when `smooth`.  A course whose samples do not fit Lmax, or
+        with repeated waypoints, raises."""
+        lib = _lib.load()
+        K = len(waypoints)
+        N = max(len(w[0]) for w in waypoints)
+        wx = np.zeros((K, N)); wy = np.zeros((K, N)); nw = np.zeros(K, dtype=np.int32)
+        longest = 0.0
+        for k, (x, y) in enumerate(waypoints):
+            n = len(x)
+            wx[k, :n], wy[k, :n], nw[k] = x, y, n
+            longest = max(longest, float(np.hypot(np.diff(x), np.diff(y)).sum()))
+        if Lmax is None:
+            Lmax = int(math.ceil(longest / ds)) + 2
+        self = cls.__new__(cls)
+        dev = _device()
+        self.K, self.Lmax = K, int(Lmax)
+        self.cx = torch.zeros((K, Lmax), dtype=torch.float64, device=dev)
+        self.cy = torch.zeros_like(self.cx)
+        self.cyaw = torch.zeros_like(self.cx)
+        self.ck = torch.zeros_like(self.cx)
+        self.clen = torch.zeros(K, dtype=torch.int32, device=dev)
+        d_wx, d_wy, d_nw = _dev(wx), _dev(wy), _dev(nw, torch.int32)
+        _lib.check(lib.mpcx_build_courses_batch(K, N, _ptr(d_wx), _ptr(d_wy), _ptr(d_nw), float(ds), int(Lmax),
+                                                1 if smooth else 0, _ptr(self.cx), _ptr(self.cy), _ptr(self.cyaw),
+                                                _ptr(self.ck), _ptr(self.clen), _stream()))
+        self.clen_host = self.clen.cpu().numpy()
+        if (self.clen_host < 0).any():
+            bad = int(np.nonzero(self.clen_host < 0)[0][0])
+            raise _lib.MpcxError(f"course {bad}: repeated or non-finite waypoints, or more than Lmax={Lmax} samples")
+        return self
 
 
 def nearest_ref_batch(mode: int, T: int, dt: float, param: float, state, course_id, pind, table: CourseTable,
