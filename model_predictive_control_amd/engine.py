@@ -276,7 +276,34 @@ class ClosedLoop:
         o["u"], self.uprev = self.uprev, o["u"]   # this optimum warm-starts the next tick
         self.n_done_ticks = k
 
+    def capture(self):
+        """Records two consecutive ticks (one per warm-start buffer) as a HIP graph; `run`
+        then replays it: 8 launches become one graph launch.  Needs the register/LDS-resident
+        solve kernels (T = 5, every bound finite): they allocate nothing.  Logging is off
+        in a captured loop.  Capturing itself advances the loop by two (warm-up) ticks."""
+        if self.log is not None:
+            raise _lib.MpcxError("a logging loop cannot be captured: the log slot changes every tick")
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.tick(); self.tick()      # warm-up on the capture stream
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        done = self.n_done_ticks
+        with torch.cuda.graph(g):
+            self.tick(); self.tick()      # an even number of ticks leaves the two u buffers in place
+        self.n_done_ticks = done          # recorded, not run
+        self._graph = g
+        return self
+
     def run(self, n_ticks: int):
+        g = getattr(self, "_graph", None)
+        while g is not None and n_ticks >= 2:
+            g.replay()
+            self.n_done_ticks += 2
+            n_ticks -= 2
         for _ in range(n_ticks):
             self.tick()
         return self

@@ -66,3 +66,18 @@ def test_goal_freezes_a_vehicle_and_failure_means_cold_start():
     loop.run(2)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(loop.state.cpu().numpy()[0], frozen)
+
+
+def test_graph_replay_equals_eager_ticks():
+    """The tick (reference window -> solve -> advance) allocates nothing, so it can be
+    recorded as a HIP graph; replaying it must give exactly the eager loop's states."""
+    B, n = 512, 8
+    engine, v, ov, table, tabs, state, cid, pind = _setup("dsr_ackermann", B, 41)
+    eager = engine.ClosedLoop(v, table, state, cid, pind0=pind).run(n + 2)
+    graph = engine.ClosedLoop(v, table, state, cid, pind0=pind).capture()   # capturing runs 2 warm-up ticks
+    graph.run(n)
+    torch.cuda.synchronize()
+    assert graph.n_done_ticks == eager.n_done_ticks == n + 2
+    for name in ("state", "twist", "target_ind", "done", "ticks", "has_prev"):
+        np.testing.assert_array_equal(getattr(graph, name).cpu().numpy(), getattr(eager, name).cpu().numpy())
+    np.testing.assert_array_equal(graph.last_u.cpu().numpy(), eager.last_u.cpu().numpy())
