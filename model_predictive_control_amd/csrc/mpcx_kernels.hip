@@ -216,7 +216,10 @@ __global__ __launch_bounds__(kWave) void k_solve_reg(SolveArgs a)
 #define MPCX_PAIR_K 5
 #endif
 constexpr int kPairIpmIters = MPCX_PAIR_K;   // interior-point iterations before the active-set rounds
-constexpr int kPairRounds0 = 6;              // active-set rounds after them
+#ifndef MPCX_PAIR_R0
+#define MPCX_PAIR_R0 6
+#endif
+constexpr int kPairRounds0 = MPCX_PAIR_R0;              // active-set rounds after them
 constexpr int kPairRounds1 = 4;              // ... and after a converged interior-point solve
 // CHAIN: the MPC.iterativeLMPC flavour (T chained QPs per call); otherwise exactly one QP.
 template <int MODEL, bool CHAIN>
@@ -350,7 +353,8 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; ++attempt) {
             int st = MPCX_ST_OK, it = 0;
-            pair::ipm(s, attempt == 0 ? (a.max_iter < kPairIpmIters ? a.max_iter : kPairIpmIters) : a.max_iter, attempt == 0, !need, st, it);
+            pair::ipm(s, attempt == 0 ? (a.max_iter < kPairIpmIters ? a.max_iter : kPairIpmIters) : a.max_iter, attempt == 0,
+                      !need, st, it);
             if (pass == 0) MPCX_STAMP(2 + 2 * attempt);
             if (need) { iters += it; status = st; }
             // the rounds run even after an interior-point solve that stalled short of its
@@ -363,6 +367,12 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a
             const bool settled = pair::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1);
 #endif
             if (pass == 0) MPCX_STAMP(3 + 2 * attempt);
+#ifdef MPCX_TRACE_B
+            if (b == MPCX_TRACE_B && live)
+                printf("b %ld lane %d pass %d attempt %d need %d ipm st %d it %d settled %d ws %g %g %g %g %g\n", (long)b,
+                       (int)threadIdx.x, pass, attempt, (int)need, st, it, (int)settled, s.ws[0], s.ws[1], s.ws[2],
+                       s.ws[3], s.ws[4]);
+#endif
             if (need && settled) status = MPCX_ST_OK;
             need = need && !settled;
             if (!__any(need)) break;

@@ -5,15 +5,11 @@ import numpy as np, torch
 from model_predictive_control_amd import engine, variants, workload, _lib
 name = sys.argv[1] if len(sys.argv) > 1 else "dsr_ackermann"
 B = 65536
-v = variants.get(name)
-courses = workload.make_courses(64)
-inst = workload.make_instances(courses, B, seed=2003)
-xref = torch.from_numpy(workload.reference_window(courses, inst, v.T)).cuda()
-x0 = torch.from_numpy(inst["state"][:, :3].copy()).cuda()
-out = engine.solve_batch(v, x0, xref)
-up = out["u"].clone()
+import bench
+bench.VARIANT = name
+v, x0, xref, up, hp = bench.build_inputs(0, B)     # tick 10 of a closed-loop run, as the benchmark times
 for _ in range(3):
-    out = engine.solve_batch(v, x0, xref, up)
+    out = engine.solve_batch(v, x0, xref, up, hp)
 torch.cuda.synchronize()
 lib = _lib.load()
 n = 2048
