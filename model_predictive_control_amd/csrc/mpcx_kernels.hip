@@ -32,11 +32,6 @@ __device__ unsigned long long g_stamps[kStampWaves * kStampSlots];
 #define MPCX_STAMP_CLEAR()
 #endif
 
-}  // namespace mpcx
-
-#include "mpcx_pair.h"
-
-namespace mpcx {
 
 // ------------------------------------------------------------------------------------
 // solve: one instance per lane
@@ -221,226 +216,27 @@ constexpr int kPairIpmIters = MPCX_PAIR_K;   // interior-point iterations before
 #endif
 constexpr int kPairRounds0 = MPCX_PAIR_R0;              // active-set rounds after them
 constexpr int kPairRounds1 = 4;              // ... and after a converged interior-point solve
-// CHAIN: the MPC.iterativeLMPC flavour (T chained QPs per call); otherwise exactly one QP.
-template <int MODEL, bool CHAIN>
-__global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void k_solve_pair(SolveArgs a)
-{
-    // LDS: Hs = input staging (x0, controls, xbar), then H and g, then output staging;
-    // Ds = stage dynamics; Xs = the wave's reference windows (read again by the epilogue)
-    __shared__ double Hs[pair::kLdsPerLane * kWave];
-    __shared__ double Ds[pair::kDynDoubles * pair::kPairs];
-    __shared__ double Xs[pair::kPairs * pair::padded(3 * (pair::TT + 1))];
-    __shared__ int Fs[kWave];
-    constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
-    constexpr int T = pair::TT, W = T + 1;
-    constexpr int SX = pair::padded(3 * W), SU = pair::padded(NU * T), S0 = pair::padded(3);   // record strides in LDS
-    constexpr int kInU = pair::kPairs * S0, kInXbar = kInU + pair::kPairs * SU;
-    static_assert(kInXbar + pair::kPairs * SX <= pair::kLdsPerLane * kWave, "input staging must fit in the H area");
-    const mpcx_variant &v = a.v;
-    pair::State s;
-    const int lane = threadIdx.x;
-    MPCX_STAMP_CLEAR();
-    MPCX_STAMP(0);
-    s.bind((pair::lds_double *)Hs, (pair::lds_double *)Ds, lane);
-    const int64_t b0 = (int64_t)blockIdx.x * pair::kPairs;
-    const int nb = a.B - b0 < pair::kPairs ? (int)(a.B - b0) : pair::kPairs;
-    const int pl = lane >> 1;
-    const bool live = pl < nb;
-    const int pc = live ? pl : nb - 1;   // idle pairs redo the wave's last instance so votes stay uniform
-    const int64_t b = b0 + pc;
+}  // namespace mpcx
 
-    pair::lds_double *stg = (pair::lds_double *)Hs, *xs = (pair::lds_double *)Xs;
-    // non-finite input raises a per-instance flag while it is staged: [0..31] state, reference
-    // and xbar; [32..63] controls (which only count for warm-started instances)
-    volatile __attribute__((address_space(3))) int *flg = (volatile __attribute__((address_space(3))) int *)Fs;
-    flg[lane] = 0;
-    bool warm;
-    {
-        pair::StageIn<pair::kPairs * 3 * W, 3 * W> in_xr, in_xb;
-        pair::StageIn<pair::kPairs * 3, 3> in_x0;
-        pair::StageIn<pair::kPairs * NU * T, NU * T> in_u;
-        in_xr.load(a.xref + b0 * 3 * W, nb * 3 * W, lane);
-        in_x0.load(a.x0 + b0 * 3, nb * 3, lane);
-        if (a.uin) in_u.load(a.uin + b0 * NU * T, nb * NU * T, lane);
-        if (a.linear_mode) in_xb.load(a.xbar + b0 * 3 * W, nb * 3 * W, lane);
-        warm = a.linear_mode || (a.uin && (!a.has_prev || a.has_prev[b]));
-        in_xr.put(nb * 3 * W, xs, lane, flg);
-        in_x0.put(nb * 3, stg, lane, flg);
-        if (a.uin) in_u.put(nb * NU * T, stg + kInU, lane, flg + pair::kPairs);
-        if (a.linear_mode) in_xb.put(nb * 3 * W, stg + kInXbar, lane, flg);
-    }
-    __builtin_amdgcn_wave_barrier();
+#define MPCX_PAIR_TT 5
+#define MPCX_PAIR_NS pair5
+#define MPCX_PAIR_KERNEL k_solve_pair5
+#include "mpcx_pair.h"
+#include "mpcx_pair_kernel.h"
+#undef MPCX_PAIR_TT
+#undef MPCX_PAIR_NS
+#undef MPCX_PAIR_KERNEL
 
-    const volatile pair::lds_double *xr = xs + pc * SX;
-    const volatile pair::lds_double *x0s = stg + pc * S0;
-    double x0[3] = {x0s[0], x0s[1], x0s[2]};
-#ifdef MPCX_STAMPS
-    if (x0[0] == 1.2345e300) return;   // forces the loads to have landed before the stamp
-#endif
-    MPCX_STAMP(8);
-    bool coldfin = true;
-#pragma unroll
-    for (int r = 0; r < NU; ++r) coldfin = coldfin && finite_d(v.cold_start[r]);
-    const bool finite = flg[pc] == 0 && (warm ? flg[pair::kPairs + pc] == 0 : coldfin);
-    pair::Lin lp;
-    lp.u = stg + kInU + pc * SU;
-    lp.cold = v.cold_start;
-    lp.warm = warm;
-    lp.has_yaw = a.linear_mode != 0;
-    lp.yaw = stg + kInXbar + pc * SX + 2 * W;
-    lp.theta0 = x0[2];
-    double u0[4] = {0.0, 0.0, 0.0, 0.0};   // first-stage controls: read before H overwrites the staging
-#pragma unroll
-    for (int r = 0; r < NU; ++r) u0[r] = lp.control(r, 0);
+#define MPCX_PAIR_TT 10
+#define MPCX_PAIR_NS pair10
+#define MPCX_PAIR_KERNEL k_solve_pair10
+#include "mpcx_pair.h"
+#include "mpcx_pair_kernel.h"
+#undef MPCX_PAIR_TT
+#undef MPCX_PAIR_NS
+#undef MPCX_PAIR_KERNEL
 
-    int status = MPCX_ST_OK, iters = 0;
-    bool skip = !finite;
-    if (!finite) {
-        status = MPCX_ST_NONFINITE;
-        x0[0] = x0[1] = x0[2] = 0.0;
-        lp.theta0 = 0.0;
-    }
-    MPCX_STAMP(9);
-    {
-        FreeBounds fb;   // the first-stage window hangs on the incoming first column, in every pass
-        free_bounds(v, u0, fb);
-        if (!fb.feasible && !skip) { skip = true; status = MPCX_ST_INFEASIBLE; }
-        s.b_ = s.odd ? fb.b[1] : fb.b[0];
-        s.rr = s.odd ? fb.rr[1] : fb.rr[0];
-        s.lo0 = s.odd ? fb.lo0[1] : fb.lo0[0];
-        s.hi0 = s.odd ? fb.hi0[1] : fb.hi0[0];
-    }
-    // MPC.iterativeLMPC solves T QPs per call, each linearised about column `pass` of the
-    // previous answer (mpc_sim.py:293-306); every other caller solves one.
-    const int chain = !CHAIN ? 1 : (v.chain < T ? v.chain : T);
-    const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
-    pair::LinRegs L;
-    bool inaccurate = false;
-    pair::prepare_lin<MODEL>(s, v, lp, CHAIN, L);
-#pragma unroll 1
-    for (int pass = 0; pass < chain; ++pass) {
-        if (CHAIN && pass > 0) {
-            // column `pass` of the linearisation controls <- the previous answer
-            double wp0 = 0.0, wp1 = 0.0;
-#pragma unroll
-            for (int t = 1; t < T; ++t) {
-                if (t == pass) {
-                    wp0 = s.odd ? s.wo[t] : s.ws[t];
-                    wp1 = s.odd ? s.ws[t] : s.wo[t];
-                }
-            }
-            double un[4];
-            if (v.eq_mode == MPCX_EQ_NONE) { un[0] = wp0; un[1] = wp1; un[2] = 0.0; un[3] = 0.0; }
-            else if (v.eq_mode == MPCX_EQ_FIXED_STEER) { un[0] = wp0; un[1] = v.steer_fixed; un[2] = wp1; un[3] = v.steer_fixed; }
-            else { un[0] = wp0; un[1] = wp1; un[2] = wp0; un[3] = sg * wp1; }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                if (L.tj[j] == pass) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) L.u[j][r] = un[r];
-                }
-            }
-        }
-        pair::stage_eval<MODEL>(s, v, L, CHAIN);
-        if (pass == 0) MPCX_STAMP(10);
-        pair::condense(s, v, x0, xr);
-        if (pass == 0) MPCX_STAMP(1);
-        // Attempt 0: a fixed, wave-uniform number of interior-point iterations, then active-set
-        // rounds that either certify the exact optimum or give up.  Attempt 1 (only for lanes
-        // attempt 0 left unsettled): interior point to convergence, then the same rounds; if
-        // those do not settle either, the converged interior-point iterate is the answer.
-        bool need = !skip;
-#pragma unroll 1
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            int st = MPCX_ST_OK, it = 0;
-            pair::ipm(s, attempt == 0 ? (a.max_iter < kPairIpmIters ? a.max_iter : kPairIpmIters) : a.max_iter, attempt == 0,
-                      !need, st, it);
-            if (pass == 0) MPCX_STAMP(2 + 2 * attempt);
-            if (need) { iters += it; status = st; }
-            // the rounds run even after an interior-point solve that stalled short of its
-            // tolerances: they certify their own answer, and a stalled iterate usually has the set
-#ifdef MPCX_STAMPS
-            int rounds = 0;
-            const bool settled = pair::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1, &rounds);
-            if (pass == 0 && attempt == 0 && threadIdx.x == 0 && blockIdx.x < kStampWaves) g_stamps[blockIdx.x * kStampSlots + 7] = rounds;
-#else
-            const bool settled = pair::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1);
-#endif
-            if (pass == 0) MPCX_STAMP(3 + 2 * attempt);
-#ifdef MPCX_TRACE_B
-            if (b == MPCX_TRACE_B && live)
-                printf("b %ld lane %d pass %d attempt %d need %d ipm st %d it %d settled %d ws %g %g %g %g %g\n", (long)b,
-                       (int)threadIdx.x, pass, attempt, (int)need, st, it, (int)settled, s.ws[0], s.ws[1], s.ws[2],
-                       s.ws[3], s.ws[4]);
-#endif
-            if (need && settled) status = MPCX_ST_OK;
-            need = need && !settled;
-            if (!__any(need)) break;
-        }
-        if (!skip && status == MPCX_ST_FAILED) skip = true;   // the reference's chain dies with its first failed solve
-        if (CHAIN && !skip && status == MPCX_ST_INACCURATE) inaccurate = true;
-    }
-    // an inaccurate link makes the whole chain's answer inaccurate, whatever the last solve says
-    if (CHAIN && inaccurate && status == MPCX_ST_OK) status = MPCX_ST_INACCURATE;
-
-    // epilogue (both lanes evaluate it; the even lane stages the controls, the odd lane the
-    // states and the objective; the wave then writes its 32 records as contiguous blocks)
-    const bool bad = status == MPCX_ST_NONFINITE || status == MPCX_ST_INFEASIBLE;
-    const double nan = __builtin_nan("");
-    double J = 0.0, qg = 1.0;
-    double x[3] = {x0[0], x0[1], x0[2]};
-    double up[4] = {0, 0, 0, 0};
-    constexpr int kOutX = pair::kPairs * SU, kOutJ = kOutX + pair::kPairs * SX;
-    volatile pair::lds_double *uo = stg + pl * SU, *xo = stg + kOutX + pl * SX;
-    const bool st_u = !s.odd, st_x = s.odd;
-    if (st_x) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) xo[r * W] = bad ? nan : x[r];
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const double w0 = s.odd ? s.wo[t] : s.ws[t], w1 = s.odd ? s.ws[t] : s.wo[t];
-        double u[4];
-        if (v.eq_mode == MPCX_EQ_NONE) { u[0] = w0; u[1] = w1; u[2] = 0.0; u[3] = 0.0; }
-        else if (v.eq_mode == MPCX_EQ_FIXED_STEER) { u[0] = w0; u[1] = v.steer_fixed; u[2] = w1; u[3] = v.steer_fixed; }
-        else { u[0] = w0; u[1] = w1; u[2] = w0; u[3] = sg * w1; }
-#pragma unroll
-        for (int r = 0; r < NU; ++r) {
-            J = fma(v.R[r] * u[r], u[r], J);
-            if (t > 0) { const double d = u[r] - up[r]; J = fma(v.Rd[r] * d, d, J); }
-            up[r] = u[r];
-            if (st_u) uo[r * T + t] = bad ? nan : u[r];
-        }
-        pair::Dyn dy;
-        pair::load_dyn(s, t, dy);
-        const double a02 = dy.a02, a12 = dy.a12;
-        const double (&bt)[3][2] = dy.bt;
-        const double (&ct)[3] = dy.ct;
-        const double n0 = x[0] + a02 * x[2] + bt[0][0] * w0 + bt[0][1] * w1 + ct[0];
-        const double n1 = x[1] + a12 * x[2] + bt[1][0] * w0 + bt[1][1] * w1 + ct[1];
-        const double n2 = x[2] + bt[2][0] * w0 + bt[2][1] * w1 + ct[2];
-        x[0] = n0; x[1] = n1; x[2] = n2;
-        const int ts = t + 1;
-        if (ts < T) qg *= v.q_growth;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double e = xr[r * W + ts] - x[r];
-            const double q = ts < T ? v.Q[r] * qg : v.Qf[r];
-            J = fma(q * e, e, J);
-            if (st_x) xo[r * W + ts] = bad ? nan : x[r];
-        }
-    }
-    if (st_x) ((volatile pair::lds_double *)stg)[kOutJ + pl] = bad ? nan : J;
-    __builtin_amdgcn_wave_barrier();
-    pair::stage_out<pair::kPairs * NU * T, NU * T>(a.u_out + b0 * NU * T, nb * NU * T, stg, lane);
-    pair::stage_out<pair::kPairs * 3 * W, 3 * W>(a.x_out + b0 * 3 * W, nb * 3 * W, stg + kOutX, lane);
-    if (lane < nb) a.obj_out[b0 + lane] = ((const volatile pair::lds_double *)stg)[kOutJ + lane];
-    if (live && !s.odd) {
-        a.status_out[b] = status;
-        if (a.iters_out) a.iters_out[b] = iters;
-    }
-    MPCX_STAMP(6);
-}
+namespace mpcx {
 
 template <int MODEL>
 __global__ __launch_bounds__(kWave) void k_solve_mem(SolveArgs a, double *ws, int64_t stride)
@@ -844,6 +640,16 @@ static bool all_present(const mpcx_variant *v)
 // the register-resident kernels are built for T = 5 with every bound present
 static bool uses_registers(const mpcx_variant *v) { return v->T == 5 && all_present(v); }
 
+// the lane-pair kernels need a finite box on both free channels; a missing rate bound is
+// replaced in the kernel by one the box makes redundant
+static bool boxes_present(const mpcx_variant *v)
+{
+    auto fin = [](double x) { return std::isfinite(x); };
+    if (v->eq_mode == MPCX_EQ_NONE) return fin(v->umax[0]) && fin(v->umax[1]);
+    if (v->eq_mode == MPCX_EQ_FIXED_STEER) return fin(v->umax[0]) && fin(v->umax[2]);
+    return (fin(v->umax[0]) || fin(v->umax[2])) && (fin(v->umax[1]) || fin(v->umax[3]));
+}
+
 // test hook: MPCX_SINGLE_LANE=1 routes T = 5 solves to the one-lane-per-instance kernel
 static const bool g_force_single_lane = [] { const char *e = getenv("MPCX_SINGLE_LANE"); return e && e[0] == '1'; }();
 
@@ -870,11 +676,11 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
         if (!g_force_single_lane) {
             const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
             if (v->model == MPCX_MODEL_DIFF_DRIVE) {
-                if (chained) hipLaunchKernelGGL((k_solve_pair<0, true>), pgrid, block, 0, st, a);
-                else hipLaunchKernelGGL((k_solve_pair<0, false>), pgrid, block, 0, st, a);
+                if (chained) hipLaunchKernelGGL((k_solve_pair5<0, true>), pgrid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_solve_pair5<0, false>), pgrid, block, 0, st, a);
             } else {
-                if (chained) hipLaunchKernelGGL((k_solve_pair<1, true>), pgrid, block, 0, st, a);
-                else hipLaunchKernelGGL((k_solve_pair<1, false>), pgrid, block, 0, st, a);
+                if (chained) hipLaunchKernelGGL((k_solve_pair5<1, true>), pgrid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_solve_pair5<1, false>), pgrid, block, 0, st, a);
             }
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return hip_fail(e, "k_solve_pair launch");
@@ -889,6 +695,15 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_solve_reg launch");
+        return 0;
+    }
+    if (v->T == 10 && boxes_present(v) && !(!a.linear_mode && v->chain > 1) && !g_force_single_lane) {
+        // the T = 10 instantiation of the lane-pair kernel (mpc.py's horizon)
+        const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave)), block(kWave);
+        if (v->model == MPCX_MODEL_DIFF_DRIVE) hipLaunchKernelGGL((k_solve_pair10<0, false>), pgrid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_solve_pair10<1, false>), pgrid, block, 0, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "k_solve_pair10 launch");
         return 0;
     }
     // memory-resident path, chunked so the workspace stays bounded
@@ -1011,6 +826,7 @@ int64_t mpcx_workspace_bytes(const mpcx_variant *v, int64_t B)
 {
     if (check_variant(v) != 0 || B < 0) return MPCX_E_ARG;
     if (uses_registers(v)) return 0;
+    if (v->T == 10 && boxes_present(v) && v->chain <= 1 && !g_force_single_lane) return 0;   // lane-pair kernel
     const int64_t chunk = B < kChunk ? ((B + kWave - 1) / kWave) * kWave : kChunk;
     return ws_doubles_per_instance(v->T) * chunk * (int64_t)sizeof(double);
 }

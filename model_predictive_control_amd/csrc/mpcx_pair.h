@@ -18,17 +18,24 @@
 // diagonal block is factored on both lanes redundantly, the panel below it is local to the
 // row owner, and only the panel entries the trailing update needs cross the pair; no
 // select on the lane parity is left in the factorisation or in the triangular solves.
-#pragma once
+//
+// This file is a template by inclusion: define MPCX_PAIR_TT (the horizon) and MPCX_PAIR_NS (the
+// namespace the instantiation lives in) before each #include; mpcx_kernels.hip includes it
+// once for T = 5 and once for T = 10.
 #include "mpcx_device.h"
 
+#if !defined(MPCX_PAIR_TT) || !defined(MPCX_PAIR_NS)
+#error "define MPCX_PAIR_TT and MPCX_PAIR_NS before including mpcx_pair.h"
+#endif
+
 namespace mpcx {
-namespace pair {
+namespace MPCX_PAIR_NS {
 
 #ifndef MPCX_PAIR_AUX
 #define MPCX_PAIR_AUX double
 #endif
 typedef MPCX_PAIR_AUX aux_t;             // storage type of the reciprocal slacks
-constexpr int TT = 5;                    // horizon = number of 2x2 block rows
+constexpr int TT = MPCX_PAIR_TT;         // horizon = number of 2x2 block rows
 constexpr int NBLK = TT * (TT + 1) / 2;  // lower-triangular blocks
 constexpr int NOFF = TT * (TT - 1) / 2;  // blocks strictly below the diagonal
 constexpr int NRT = TT - 1;              // rate constraints per channel and side
@@ -638,13 +645,14 @@ __device__ __forceinline__ void load_dyn(const State &s, int t, Dyn &d)
     }
 }
 
-// Linearisation point of the lane's own stages (even lane: stages 0, 2, 4; odd lane: 1, 3 and
-// 4 again), kept in registers over the solves of one call.
+// Linearisation point of the lane's own stages (even lane: stages 0, 2, 4, ...; odd lane: 1, 3,
+// ... and, for an odd horizon, the last stage again), kept in registers while it is needed.
+constexpr int NSLOT = (TT + 1) / 2;
 struct LinRegs {
-    double u[3][4];    // controls at the linearisation point
-    double th[3];      // yaw at the linearisation point
-    SteerTerms k[3];   // sines / cosines of the steer angles of u
-    int tj[3];         // which stage each slot is
+    double u[NSLOT][4];    // controls at the linearisation point
+    double th[NSLOT];      // yaw at the linearisation point
+    SteerTerms k[NSLOT];   // sines / cosines of the steer angles of u
+    int tj[NSLOT];         // which stage each slot is
 };
 
 // Controls and yaw of the lane's stages from the staged inputs.  The yaw is rolled from the
@@ -659,7 +667,7 @@ __device__ __forceinline__ void prepare_lin(const State &s, const mpcx_variant &
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     const bool odd = s.odd;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NSLOT; ++j) {
         int t = 2 * j + (odd ? 1 : 0);
         t = t < TT ? t : TT - 1;
         L.tj[j] = t;
@@ -671,22 +679,23 @@ __device__ __forceinline__ void prepare_lin(const State &s, const mpcx_variant &
     }
     if (lp.has_yaw) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) L.th[j] = lp.yaw[L.tj[j]];
+        for (int j = 0; j < NSLOT; ++j) L.th[j] = lp.yaw[L.tj[j]];
     } else {
-        const double w0 = from_even(L.k[0].omega), w1 = from_odd(L.k[0].omega);
-        const double w2 = from_even(L.k[1].omega), w3 = from_odd(L.k[1].omega);
-        const double t0 = lp.theta0;
-        const double t1 = t0 + w0 * v.dt;
-        const double t2 = t1 + w1 * v.dt;
-        const double t3 = t2 + w2 * v.dt;
-        const double t4 = t3 + w3 * v.dt;
-        L.th[0] = odd ? t1 : t0;
-        L.th[1] = odd ? t3 : t2;
-        L.th[2] = t4;
+        double th = lp.theta0;   // yaw at stage 2j (even lane's slot j), then at stage 2j + 1
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const double we = from_even(L.k[j].omega), wo = from_odd(L.k[j].omega);
+            const double th_even = th;
+            const double th_odd = th_even + we * v.dt;
+            // for an odd horizon the odd lane's last slot repeats the last (even) stage
+            const bool repeat = 2 * j + 1 >= TT;
+            L.th[j] = (odd && !repeat) ? th_odd : th_even;
+            th = th_odd + wo * v.dt;
+        }
     }
     if (chained) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < NSLOT; ++j) {
             if (L.tj[j] > 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) L.u[j][r] = 0.0;
@@ -702,10 +711,10 @@ __device__ __forceinline__ void stage_eval(State &s, const mpcx_variant &v, LinR
 {
     if (fresh) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) steer_terms<MODEL>(v, L.u[j], L.k[j]);
+        for (int j = 0; j < NSLOT; ++j) steer_terms<MODEL>(v, L.u[j], L.k[j]);
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < NSLOT; ++j) {
         double a02, a12, Bm[3][4], C[3], bt[3][2], ct[3];
         linearize_at<MODEL>(v, L.th[j], L.u[j], L.k[j], a02, a12, Bm, C);
         reduce_controls(v, Bm, C, bt, ct);
@@ -813,5 +822,5 @@ __device__ __forceinline__ void condense(State &s, const mpcx_variant &v, const 
     for (int I = 0; I < TT; ++I) s.lds[(2 * NBLK + I) * kWave] = gacc[I];
 }
 
-}  // namespace pair
+}  // namespace MPCX_PAIR_NS
 }  // namespace mpcx

@@ -179,6 +179,41 @@ def test_infeasible_nonfinite_and_tiny_batches(eng):
     assert out["u"].shape[0] == 0
 
 
+def test_mpc_py_horizon_10_lane_pair_kernel(eng):
+    """mpc.py's controller (T = 10, dt = 0.1, input-difference cost, no rate bound on the
+    speeds) runs on the T = 10 instantiation of the lane-pair kernel: ragged batch, warm/cold
+    mix, non-finite and infeasible instances, tiny batches, and the one-QP entry point."""
+    B = 2048 + 21
+    v, ov, x0, xref = make_problem("mpc_py", B, seed=13)
+    ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
+    out = eng.solve_batch(v, x0, xref)
+    compare(out, ref)
+    hp = (np.arange(B) % 4 != 0).astype(np.uint8)
+    up = ref["u"].copy()
+    up[7, 1, 0] = 3.5           # first-step window outside the steer box -> infeasible
+    up[7, 3, 0] = -3.5
+    x0b, xrefb = x0.copy(), xref.copy()
+    x0b[11, 0] = np.nan
+    xrefb[19, 1, 10] = np.inf
+    ref2 = orc.iterative_batch(ov, x0b, xrefb, up, hp, nthreads=8)
+    assert ref2["status"][7] == O.ST_INFEASIBLE and ref2["status"][11] == O.ST_NONFINITE and ref2["status"][19] == O.ST_NONFINITE
+    out2 = eng.solve_batch(v, x0b, xrefb, up, hp)
+    compare(out2, ref2)
+    for n in (1, 31, 33, 64):
+        outn = eng.solve_batch(v, x0b[:n], xrefb[:n], up[:n], hp[:n])
+        compare(outn, {k: a[:n] for k, a in ref2.items()})
+    # linear_mpc_control at an arbitrary linearisation point (controlLaw, mpc.py:117-187)
+    n = 512
+    rng = np.random.default_rng(2)
+    uref = np.zeros((n, 4, 10))
+    uref[:, 0] = rng.uniform(-0.4, 0.4, (n, 10)); uref[:, 2] = uref[:, 0]
+    uref[:, 1] = rng.uniform(-0.5, 0.5, (n, 10)); uref[:, 3] = -uref[:, 1]
+    xbar = orc.rollout_batch(ov, x0[:n], uref)
+    refl = orc.linear_mpc_batch(ov, xref[:n], xbar, x0[:n], uref, nthreads=8)
+    outl = eng.linear_mpc_batch(v, xref[:n], xbar, x0[:n], uref)
+    compare(outl, refl)
+
+
 def test_long_horizons_memory_path(eng):
     for name, T, B in (("mpc_py", 10, 1024), ("dsr_ackermann", 30, 512), ("diff_drive", 12, 512)):
         v, ov, x0, xref = make_problem(name, B, T=T)
