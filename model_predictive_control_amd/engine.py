@@ -70,6 +70,34 @@ def solve_batch(v: CVariant, x0, xref, uprev=None, has_prev=None, out=None) -> D
     return out
 
 
+def solve_mixed(variant_list, variant_id, x0, xref, uprev=None, has_prev=None) -> Dict[str, torch.Tensor]:
+    """A batch whose instances use different variants of one shape (same NU and T): instances are
+    grouped by variant so that every wavefront is homogeneous, each group is one launch, and the
+    results come back in the caller's order.  variant_id [B] indexes variant_list."""
+    x0, xref = _dev(x0), _dev(xref)
+    vid = _dev(variant_id, torch.int64)
+    B = x0.shape[0]
+    nu, T = variant_list[0].nu, variant_list[0].T
+    if any(v.nu != nu or v.T != T for v in variant_list):
+        raise ValueError("solve_mixed needs variants of one shape (same NU and T)")
+    uprev = None if uprev is None else _dev(uprev)
+    has_prev = None if has_prev is None else _dev(has_prev, torch.uint8)
+    order = torch.argsort(vid, stable=True)
+    counts = torch.bincount(vid, minlength=len(variant_list)).cpu().tolist()
+    out = _outputs(B, nu, T, x0.device)
+    start = 0
+    for k, n in enumerate(counts):
+        if n == 0:
+            continue
+        idx = order[start:start + n]
+        part = solve_batch(variant_list[k], x0[idx], xref[idx], None if uprev is None else uprev[idx],
+                           None if has_prev is None else has_prev[idx])
+        for key in out:
+            out[key][idx] = part[key]
+        start += n
+    return out
+
+
 def linear_mpc_batch(v: CVariant, xref, xbar, x0, uref, out=None) -> Dict[str, torch.Tensor]:
     """linear_mpc_control* for B instances at the linearisation point (xbar, uref)."""
     lib = _lib.load()

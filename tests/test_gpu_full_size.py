@@ -118,3 +118,21 @@ def test_four_million_mixed_instances_tile_identically():
         assert bool((out["obj"].view(tiles, base) == out["obj"].view(tiles, base)[0:1]).all().item())
         first = u[0].cpu().numpy()
         assert _constraint_violation(ov, first, np.asarray(ov.cold_start)[:ov.nu][None]) <= 1e-9
+
+
+def test_mixed_variant_batch_equals_separate_solves():
+    """Instances of four variants interleaved in one batch (sorted by variant inside, so every
+    wavefront is homogeneous) give exactly what four separate batches give."""
+    from model_predictive_control_amd import engine, variants
+    names = ["dsr_ackermann", "dsr_crab", "dsr_diff", "sim_ackermann"]
+    vs = [variants.get(n) for n in names]
+    B = 4096 + 5
+    _, _, x0, xref = make_problem("dsr_ackermann", B, seed=29)
+    rng = np.random.default_rng(1)
+    vid = rng.integers(0, len(names), B)
+    out = engine.solve_mixed(vs, vid, x0, xref)
+    for k, v in enumerate(vs):
+        sel = np.nonzero(vid == k)[0]
+        part = engine.solve_batch(v, x0[sel], xref[sel])
+        for key in ("u", "x", "obj", "status", "iters"):
+            np.testing.assert_array_equal(out[key].cpu().numpy()[sel], part[key].cpu().numpy())
