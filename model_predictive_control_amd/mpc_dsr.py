@@ -10,7 +10,7 @@ import math
 
 import numpy as np
 
-from . import _scalar, variants
+from . import _scalar, trajectory_io, variants
 
 NX = 3
 NU = 4
@@ -208,3 +208,17 @@ def makeEightShapeTrajectory(n, size):
         dy = math.cos(1 * math.pi / 60 * i) * 1 * math.pi / 60
         yaw.append(math.atan2(dy, dx))
     return x, y, yaw
+
+
+# --- recorded-trajectory preprocessing (mpc_dsr.py:696-786) ---------------------------------
+
+def retriveReferenceFromCSV(file_name):
+    return trajectory_io.read_nodes_csv(file_name)
+
+
+def interpolateReference(node_lists, interpolate_num=5, mode='ackermann'):
+    return trajectory_io.interpolate_nodes(node_lists, interpolate_num, mode)
+
+
+def removeRepeatedPoints(cx, cy, cyaw, epsilon=0.00001):
+    return trajectory_io.remove_repeated_points(cx, cy, cyaw, epsilon)

@@ -12,7 +12,7 @@ import math
 
 import numpy as np
 
-from . import _scalar, variants
+from . import _scalar, trajectory_io, variants
 
 
 def smooth_yaw(yaw):
@@ -203,8 +203,23 @@ class MPC:
 
 
 class TrajectoryGenerator:
-    """Only the synthetic course of mpc_sim.py:692-703; CSV ingest and the ICR-arc
-    interpolators (mpc_sim.py:560-690) are offline preprocessing and not provided."""
+    """mpc_sim.py:554-703: CSV ingest, interpolation between recorded nodes, de-duplication,
+    splitting by motion mode (all in trajectory_io.py) and the synthetic figure-eight."""
+
+    def retriveTrajectoryFromCSV(self, file_name):
+        return trajectory_io.read_nodes_csv(file_name, with_mode=True)
+
+    def interpolateReference(self, node_lists, interpolate_num=5, mode='ackermann'):
+        return trajectory_io.interpolate_nodes(node_lists, interpolate_num, mode)
+
+    def interpolateReference2(self, node_lists, interpolate_num=5):
+        return trajectory_io.interpolate_nodes_by_mode(node_lists, interpolate_num)
+
+    def removeRepeatedPoints(self, cx, cy, cyaw, epsilon=0.00001):
+        return trajectory_io.remove_repeated_points(cx, cy, cyaw, epsilon)
+
+    def splitTrajectoryWithMotionModes(self, cmode):
+        return trajectory_io.split_by_motion_mode(cmode)
 
     def makeEightShapeTrajectory(self, size=10, n=121):
         x, y, yaw = [], [], []

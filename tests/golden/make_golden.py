@@ -217,6 +217,43 @@ def main():
         poses.append(pose.reshape(3))
     g.update(mpcpy_prune_pose=np.array(poses), mpcpy_prune_xref=np.array(prn), mpcpy_prune_len=np.array(lens))
 
+    # ---- node-list preprocessing: ICR-arc / crab interpolation, de-duplication, mode split ------
+    # synthetic node lists in the CSV schema x | y | yaw | vx | vy | w | ... | time | mode
+    n_nodes = 14
+    nodes = np.zeros((n_nodes, 11))
+    nodes[:, 0] = np.cumsum(rng.uniform(0.2, 1.0, n_nodes))
+    nodes[:, 1] = rng.uniform(-1.0, 1.0, n_nodes)
+    nodes[:, 2] = np.cumsum(rng.uniform(-0.3, 0.3, n_nodes))
+    nodes[:, 3] = rng.uniform(0.1, 0.5, n_nodes)
+    nodes[:, 4] = rng.uniform(-0.2, 0.2, n_nodes)
+    nodes[:, 5] = rng.uniform(-0.6, 0.6, n_nodes)
+    nodes[[3, 8], 5] = 0.0                       # w == 0 segments are skipped by the arc interpolator
+    nodes[:, 6:10] = rng.uniform(-1, 1, (n_nodes, 4))
+    nodes[:, 10] = np.arange(n_nodes) * 0.2
+    modes = ["ackermann"] * 4 + ["crab"] * 3 + ["diff"] * 4 + ["crab"] * 3
+    g["nodes"] = nodes
+    g["nodes_mode"] = np.array([["ackermann", "crab", "diff"].index(m) for m in modes])
+    node_list = [list(r) for r in nodes]
+    node_list_m = [list(r) + [m] for r, m in zip(nodes, modes)]
+    gen = sim.TrajectoryGenerator()
+    for k_int in (5, 3):
+        for md in ("ackermann", "crab"):
+            px, py, pyaw = dsr.interpolateReference(node_list, interpolate_num=k_int, mode=md)
+            g[f"interp_{md}_{k_int}"] = np.array([px, py, pyaw])
+            sx_, sy_, syaw_ = gen.interpolateReference(node_list, interpolate_num=k_int, mode=md)
+            assert np.array_equal(np.array([sx_, sy_, syaw_]), g[f"interp_{md}_{k_int}"])   # the two files agree
+    px, py, pyaw, pm = gen.interpolateReference2(node_list_m, interpolate_num=5)
+    g["interp2_xyyaw"] = np.array([px, py, pyaw])
+    g["interp2_mode"] = np.array([["ackermann", "crab", "diff"].index(m) for m in pm])
+    g["split_groups"] = np.array(gen.splitTrajectoryWithMotionModes(pm))
+    g["split_groups_short"] = np.array(gen.splitTrajectoryWithMotionModes(["crab", "crab", "diff", "diff", "diff", "crab"]))
+    rx_ = [0.0, 0.001, 0.002, 0.5, 0.5, 0.501, 1.0, 1.0]
+    ry_ = [0.0, 0.001, 0.0, 0.2, 0.2, 0.2, 0.4, 0.4]
+    ryaw_ = [0.0, 0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7]
+    g["dedup_in"] = np.array([rx_, ry_, ryaw_])
+    g["dedup_out"] = np.array(dsr.removeRepeatedPoints(rx_, ry_, ryaw_))
+    assert np.array_equal(np.array(gen.removeRepeatedPoints(rx_, ry_, ryaw_)), g["dedup_out"])
+
     np.savez_compressed(OUT, **g)
     print("wrote", OUT, "with", len(g), "arrays,", os.path.getsize(OUT), "bytes")
 
