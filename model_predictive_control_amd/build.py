@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "mpcx_kernels.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "mpcx_device.h"), os.path.join(HERE, "csrc", "mpcx_pair.h"), os.path.join(ROOT, "include", "mpcx.h")]
+DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))) + [os.path.join(ROOT, "include", "mpcx.h")]
 OUT = os.path.join(HERE, "lib", "libmpcx.so")
 LOG = os.path.join(HERE, "lib", "build_resource_usage.txt")
 

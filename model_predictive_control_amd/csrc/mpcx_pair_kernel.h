@@ -107,6 +107,7 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
     MPCX_PAIR_NS::LinRegs L;
     bool inaccurate = false;
     MPCX_PAIR_NS::prepare_lin<MODEL>(s, v, lp, CHAIN, L);
+    MPCX_STAMP(11);
 #pragma unroll 1
     for (int pass = 0; pass < chain; ++pass) {
         if (CHAIN && pass > 0) {
@@ -196,6 +197,16 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
 #pragma unroll
         for (int r = 0; r < 3; ++r) xo[r * W] = bad ? nan : x[r];
     }
+    // all LDS reads of the epilogue up front (the solver's registers are free now), so that the
+    // arithmetic below does not wait on them one by one
+    MPCX_PAIR_NS::Dyn dyn_all[T];
+    double xr_all[3][T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        MPCX_PAIR_NS::load_dyn(s, t, dyn_all[t]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xr_all[r][t] = xr[r * W + t + 1];
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const double w0 = s.odd ? s.wo[t] : s.ws[t], w1 = s.odd ? s.ws[t] : s.wo[t];
@@ -210,8 +221,7 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
             up[r] = u[r];
             if (st_u) uo[r * T + t] = bad ? nan : u[r];
         }
-        MPCX_PAIR_NS::Dyn dy;
-        MPCX_PAIR_NS::load_dyn(s, t, dy);
+        const MPCX_PAIR_NS::Dyn &dy = dyn_all[t];
         const double a02 = dy.a02, a12 = dy.a12;
         const double (&bt)[3][2] = dy.bt;
         const double (&ct)[3] = dy.ct;
@@ -223,13 +233,14 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
         if (ts < T) qg *= v.q_growth;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const double e = xr[r * W + ts] - x[r];
+            const double e = xr_all[r][t] - x[r];
             const double q = ts < T ? v.Q[r] * qg : v.Qf[r];
             J = fma(q * e, e, J);
             if (st_x) xo[r * W + ts] = bad ? nan : x[r];
         }
     }
     if (st_x) ((volatile MPCX_PAIR_NS::lds_double *)stg)[kOutJ + pl] = bad ? nan : J;
+    MPCX_STAMP(12);
     __builtin_amdgcn_wave_barrier();
     MPCX_PAIR_NS::stage_out<MPCX_PAIR_NS::kPairs * NU * T, NU * T>(a.u_out + b0 * NU * T, nb * NU * T, stg + kOutU, lane);
     MPCX_PAIR_NS::stage_out<MPCX_PAIR_NS::kPairs * 3 * W, 3 * W>(a.x_out + b0 * 3 * W, nb * 3 * W, stg + kOutX, lane);

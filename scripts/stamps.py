@@ -23,8 +23,8 @@ print("wave iters (max over 32 instances): mean", its.mean(), "instance mean", o
       "status counts", np.bincount(out["status"].cpu().numpy(), minlength=5))
 fb = st[:, 5] > 0
 end_solve = np.where(fb, st[:, 5], st[:, 3])
-ph = {"load": st[:, 8] - st[:, 0], "checks": st[:, 9] - st[:, 8], "stage_split": st[:, 10] - st[:, 9], "condense": st[:, 1] - st[:, 10], "ipm0": st[:, 2] - st[:, 1], "pdas0": st[:, 3] - st[:, 2],
-      "fallback": np.where(fb, st[:, 5] - st[:, 3], 0), "epilogue": st[:, 6] - end_solve, "total": st[:, 6] - st[:, 0]}
+ph = {"load": st[:, 8] - st[:, 0], "checks": st[:, 9] - st[:, 8], "prepare_lin": st[:, 11] - st[:, 9], "stage_eval": st[:, 10] - st[:, 11], "condense": st[:, 1] - st[:, 10], "ipm0": st[:, 2] - st[:, 1], "pdas0": st[:, 3] - st[:, 2],
+      "fallback": np.where(fb, st[:, 5] - st[:, 3], 0), "epilogue_compute": st[:, 12] - end_solve, "epilogue_store": st[:, 6] - st[:, 12], "total": st[:, 6] - st[:, 0]}
 print("active-set rounds per wave: mean", st[:, 7].mean(), "hist", np.bincount(st[:, 7].astype(int)))
 print("waves taking the fallback:", int(fb.sum()), "of", n)
 for nm, d in ph.items():
