@@ -29,7 +29,7 @@ from model_predictive_control_amd import engine, sharding, variants, workload  #
 VARIANT = "dsr_ackermann"
 BATCH = 65536
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
-SOLVE_KERNEL = "k_solve_pair<dual-steer>"   # two lanes per instance, T=5, everything on chip
+SOLVE_KERNEL = "k_solve_pair5<dual-steer, single QP>"   # two lanes per instance, T=5, everything on chip
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 
 
@@ -186,6 +186,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic() if B == BATCH else None,
                          "kernel": SOLVE_KERNEL, "kernel_ms": kernel_s * 1e3,
+                         "kernel_ms_note": "HIP events on the launch stream, back-to-back launches: includes the ~4 us "
+                                           "dispatch gap between consecutive kernels that a kernel trace leaves out",
                          "algorithmic_bytes_per_solve": algorithmic_bytes(v.nu, v.T),
                          "note": "the solve is FP64-VALU issue bound (5 interior-point iterations + ~4 active-set "
                                  "rounds, one 10x10 Cholesky each, per instance); HBM fraction reported as the task asks"},
