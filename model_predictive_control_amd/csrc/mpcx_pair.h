@@ -1,9 +1,9 @@
-// Two lanes per MPC instance (T = 5, every bound present).
+// Two lanes per MPC instance (horizon TT = 5 or 10, a finite box on both free channels).
 //
 // The condensed QP has 2 free controls per stage; variable 2t + c belongs to channel c.
-// Lane parity c owns channel c: its five controls, its box and rate constraints (all of
+// Lane parity c owns channel c: its TT controls, its box and rate constraints (all of
 // them couple controls of one channel only), and rows 2t + c of the symmetric matrices.
-// That halves the per-lane state, so the whole solve stays in registers with nothing
+// That halves the per-lane state: at TT = 5 the whole solve stays in registers with nothing
 // spilled to memory.  Partner values travel by DPP quad permutes (no LDS, no divergence).
 //
 // H (constant over the solve) lives in LDS by 2x2 blocks (I, J), J <= I, two entries per
@@ -227,12 +227,14 @@ __device__ __forceinline__ void add_rate(State &s, int i, double dd)
     s.D[oi(i + 1, i)] = fma(-s.mO, dd, s.D[oi(i + 1, i)]);
 }
 
-// Mehrotra predictor-corrector on the lane pair.  See ipm_solve() in mpcx_device.h for the
-// formulas; here every constraint loop runs over the lane's own channel and the scalar
-// reductions are completed with the partner.
+// Predictor-corrector interior point on the lane pair (formulas as in ipm_solve() of
+// mpcx_device.h, except that the centring parameter comes from the predictor's step lengths,
+// sigma = (1 - alpha_aff)^3, which costs no pass over the constraints); every constraint loop
+// runs over the lane's own channel and the scalar reductions are completed with the partner.
 // `fixed`: a lane runs exactly max_iter iterations (no pass is spent on a convergence test
 // after the last one) and reports MPCX_ST_FAILED unless it converged on the way; max_iter
-// may differ between lanes, the wave loops until its last lane is through.
+// may differ between lanes, the wave loops until its last lane is through.  A step that is
+// not finite (a factorisation that broke down) ends the lane's solve at the iterate it has.
 __device__ __forceinline__ void ipm(State &s, int max_iter, bool fixed, bool skip, int &status, int &iters)
 {
     // Start: every stage at the middle of the first-stage window (strictly feasible: all

@@ -62,7 +62,7 @@ def main():
     u4 = np.stack([rng.uniform(-0.6, 0.6, N), rng.uniform(-1.7, 1.7, N),
                    rng.uniform(-0.6, 0.6, N), rng.uniform(-1.7, 1.7, N)], axis=1)
     u4[0] = 0.0                      # cold-start operating point
-    u4[1] = (0.3, 0.2, 0.3, -0.2)    # the known answer quoted in the survey
+    u4[1] = (0.3, 0.2, 0.3, -0.2)    # a hand-checked known answer
     th4 = rng.uniform(-4.0, 4.0, N)
     th4[1] = 0.4
     for tag, fn in (("dsr", lambda t, u: dsr.get_linear_model_matrix(t, u[0], u[1], u[2], u[3])),
@@ -165,7 +165,7 @@ def main():
             else:
                 x, y = cx[j] + rng.normal(0, 0.3), cy[j] + rng.normal(0, 0.3)
             rows.append((c, x, y, cyaw[j] + rng.normal(0, 0.2), rng.uniform(-0.5, 0.5), pind))
-    rows.append((0, ex[0], ey[0], eyaw[0], 0.0, 0))                  # the survey's known answer
+    rows.append((0, ex[0], ey[0], eyaw[0], 0.0, 0))                  # a hand-checked known answer
     rows = np.array(rows)
     n = rows.shape[0]
     ind1 = np.zeros(n, dtype=np.int64); mind1 = np.zeros(n); mind_sim = np.zeros(n)

