@@ -1005,12 +1005,14 @@ __device__ __forceinline__ bool polish(S &s, const FreeBounds &fb, bool skip)
                 for (int i = 0; i < N; ++i) s.w(i) += s.hw(i);
             }
         }
-        // acceptance: stationary, every constraint satisfied, multipliers non-negative, close by
-        double viol = 0.0, neg = 0.0, far = 0.0, cact = 0.0;
+        // acceptance: stationary, every constraint satisfied, multipliers non-negative: the KKT
+        // conditions of a strictly convex QP, so an accepted point is its minimiser wherever
+        // the interior-point iterate stood.  max() drops NaN operands; the running sum does not.
+        double viol = 0.0, neg = 0.0, chk = 0.0, cact = 0.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const double wi = s.w(i);
-            far = dmax(far, fabs(wi - s.G(0, i)));
+            chk += wi + s.dw(i);
             if (hasbox(i)) {
                 viol = dmax(viol, dmax(wi - hi_of(i), lo_of(i) - wi));
                 cact = dmax(cact, dmax(s.isu(i) * fabs(wi - hi_of(i)), s.isl(i) * fabs(lo_of(i) - wi)));
@@ -1027,7 +1029,7 @@ __device__ __forceinline__ bool polish(S &s, const FreeBounds &fb, bool skip)
             }
         }
         if (!settled) {
-            const bool sane = stat <= 1e-10 * scale && far <= 1e-3;   // NaN fails both
+            const bool sane = finite_d(chk) && stat <= 1e-10 * scale;
             if (sane && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) { accepted = true; settled = true; }
             else if (!sane) settled = true;   // not an active-set problem: keep the iterate
         }

@@ -136,10 +136,12 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
         if (!skip) {
             iters += it;
             status = st;
-            if (st == MPCX_ST_FAILED) skip = true;
         }
+        // the polish runs even after an interior-point solve that stalled short of its
+        // tolerances: it certifies its own answer, and a stalled iterate usually has the set
         const bool polished = polish<ALL>(s, fb, skip);
         if (!skip && polished) status = MPCX_ST_OK;
+        if (!skip && status == MPCX_ST_FAILED) skip = true;
     }
 
     // controls, predicted states (the linearised dynamics re-evaluated stage by stage),
