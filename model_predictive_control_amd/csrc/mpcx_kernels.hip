@@ -220,6 +220,8 @@ constexpr int kPairRounds0 = MPCX_PAIR_R0;              // active-set rounds aft
 constexpr int kPairRounds1 = 4;              // ... and after a converged interior-point solve
 }  // namespace mpcx
 
+#include "mpcx_wave.h"
+
 #define MPCX_PAIR_TT 5
 #define MPCX_PAIR_NS pair5
 #define MPCX_PAIR_KERNEL k_solve_pair5
@@ -239,6 +241,246 @@ constexpr int kPairRounds1 = 4;              // ... and after a converged interi
 #undef MPCX_PAIR_KERNEL
 
 namespace mpcx {
+
+// ------------------------------------------------------------------------------------
+// solve: one wavefront per instance (horizons beyond the lane-pair kernels, n = 2T <= 64)
+// ------------------------------------------------------------------------------------
+constexpr int kWaveIpmIters = 6;   // interior-point iterations before the active-set rounds
+constexpr int kWaveRounds0 = 8, kWaveRounds1 = 5;
+
+__host__ __device__ inline int wave_lds_doubles(int T)
+{
+    const int n = 2 * T, S = n | 1;
+    return 2 * n * S + kWave + 11 * T + (T + 1) + 3 * kWave;   // H, K, broadcast buffer, dynamics, yaw, G rows
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
+{
+    extern __shared__ double smem[];
+    constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
+    const mpcx_variant &v = a.v;
+    const int T = v.T, W = T + 1, n = 2 * T, S = n | 1;
+    const int lane = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    wave::Ctx c;
+    c.H = (volatile wave::lds_double *)smem;
+    c.K = c.H + n * S;
+    c.vec = c.K + n * S;
+    volatile wave::lds_double *dyn = c.vec + kWave, *th = dyn + 11 * T, *Gs = th + (T + 1);
+    c.n = n; c.S = S; c.lane = lane; c.act = lane < n; c.row = c.act ? lane : 0;
+    const int st_own = c.act ? lane >> 1 : T - 1, ch = lane & 1;   // the lane's stage and channel
+
+    const double *__restrict__ xr = a.xref + b * 3 * W;
+    double x0[3] = {a.x0[b * 3], a.x0[b * 3 + 1], a.x0[b * 3 + 2]};
+    const double *uin = a.uin ? a.uin + b * NU * T : nullptr;
+    const bool warm = a.linear_mode || (uin && (!a.has_prev || a.has_prev[b]));
+    // inputs: every lane checks a slice, the wave votes
+    bool fin = finite_d(x0[0]) && finite_d(x0[1]) && finite_d(x0[2]);
+    for (int i = lane; i < 3 * W; i += kWave) fin = fin && finite_d(xr[i]);
+    if (a.linear_mode)
+        for (int i = lane; i < 3 * W; i += kWave) fin = fin && finite_d(a.xbar[b * 3 * W + i]);
+    double u[4] = {0.0, 0.0, 0.0, 0.0}, u0[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < NU; ++r) {
+        u[r] = warm ? uin[r * T + st_own] : v.cold_start[r];
+        u0[r] = warm ? uin[r * T] : v.cold_start[r];
+        fin = fin && finite_d(u[r]);
+    }
+    const bool finite = __all(fin) != 0;
+    int status = MPCX_ST_OK, iters = 0;
+    bool skip = !finite;
+    if (!finite) {
+        status = MPCX_ST_NONFINITE;
+        x0[0] = x0[1] = x0[2] = 0.0;
+    }
+
+    // stage dynamics: lanes 2t and 2t + 1 evaluate stage t; the yaw is rolled in stage order
+    SteerTerms kt;
+    steer_terms<MODEL>(v, u, kt);
+    if (a.linear_mode) {
+        if (c.act && ch == 0) th[st_own] = a.xbar[b * 3 * W + 2 * W + st_own];
+    } else {
+        if (c.act && ch == 0) c.vec[st_own] = kt.omega;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            double t0 = x0[2];
+            for (int t = 0; t < T; ++t) { th[t] = t0; t0 = t0 + c.vec[t] * v.dt; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        double a02, a12, Bm[3][4], C[3], bt[3][2], ct[3];
+        linearize_at<MODEL>(v, th[st_own], u, kt, a02, a12, Bm, C);
+        reduce_controls(v, Bm, C, bt, ct);
+        if (c.act && ch == 0) {
+            volatile wave::lds_double *p = dyn + 11 * st_own;
+            p[0] = a02; p[1] = a12;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { p[2 + 2 * r] = bt[r][0]; p[3 + 2 * r] = bt[r][1]; p[8 + r] = ct[r]; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // bounds of the lane's control
+    {
+        FreeBounds fb;
+        free_bounds(v, u0, fb);
+        if (!fb.feasible && !skip) { skip = true; status = MPCX_ST_INFEASIBLE; }
+        const bool first = st_own == 0;
+        const bool box0 = ch ? fb.box0[1] : fb.box0[0], box = ch ? fb.box[1] : fb.box[0], rate = ch ? fb.rate[1] : fb.rate[0];
+        const double bb = ch ? fb.b[1] : fb.b[0];
+        c.hb = c.act && (first ? box0 : box);
+        c.lo = first ? (ch ? fb.lo0[1] : fb.lo0[0]) : -bb;
+        c.hi = first ? (ch ? fb.hi0[1] : fb.hi0[0]) : bb;
+        c.hr = c.act && lane < n - 2 && rate;
+        c.rr = ch ? fb.rr[1] : fb.rr[0];
+        const double m = wave::wsum((c.hb ? 2.0 : 0.0) + (c.hr ? 2.0 : 0.0));
+        c.inv_m = m > 0.0 ? 1.0 / m : 0.0;
+    }
+
+    // condensed QP: row `lane` of H into LDS, g in a register
+    {
+        double rw[2], rdw[2];
+        if (v.eq_mode == MPCX_EQ_NONE) {
+            rw[0] = v.R[0]; rw[1] = v.R[1]; rdw[0] = v.Rd[0]; rdw[1] = v.Rd[1];
+        } else if (v.eq_mode == MPCX_EQ_FIXED_STEER) {
+            rw[0] = v.R[0]; rw[1] = v.R[2]; rdw[0] = v.Rd[0]; rdw[1] = v.Rd[2];
+        } else {
+            rw[0] = v.R[0] + v.R[2]; rw[1] = v.R[1] + v.R[3];
+            rdw[0] = v.Rd[0] + v.Rd[2]; rdw[1] = v.Rd[1] + v.Rd[3];
+        }
+        const double rwc = ch ? rw[1] : rw[0], rdc = ch ? rdw[1] : rdw[0];
+        if (c.act) {
+            for (int k = 0; k < n; ++k) c.H[k * S + lane] = 0.0;
+            double d = 2.0 * rwc;
+            if (st_own > 0) { d += 2.0 * rdc; c.H[(lane - 2) * S + lane] = -2.0 * rdc; }
+            if (st_own + 1 < T) { d += 2.0 * rdc; c.H[(lane + 2) * S + lane] = -2.0 * rdc; }
+            c.H[lane * S + lane] = d;
+        }
+        double p[3] = {x0[0], x0[1], x0[2]}, G[3] = {0.0, 0.0, 0.0}, gacc = 0.0, qg = 1.0;
+        for (int t = 0; t < T; ++t) {
+            volatile wave::lds_double *d = dyn + 11 * t;
+            const double a02 = d[0], a12 = d[1];
+            const double ct0 = d[8], ct1 = d[9], ct2 = d[10];
+            const double pn0 = p[0] + a02 * p[2] + ct0;
+            const double pn1 = p[1] + a12 * p[2] + ct1;
+            const double pn2 = p[2] + ct2;
+            p[0] = pn0; p[1] = pn1; p[2] = pn2;
+            if (lane < 2 * t) {
+                G[0] = fma(a02, G[2], G[0]);
+                G[1] = fma(a12, G[2], G[1]);
+            }
+            if (c.act && st_own == t) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) G[r] = d[2 + 2 * r + ch];
+            }
+            const int ts = t + 1;
+            double Qs[3];
+            if (ts < T) {
+                qg *= v.q_growth;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) Qs[r] = v.Q[r] * qg;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) Qs[r] = v.Qf[r];
+            }
+            double gi[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                Gs[r * kWave + lane] = G[r];
+                gi[r] = 2.0 * Qs[r] * G[r];
+                gacc = fma(gi[r], p[r] - xr[r * W + ts], gacc);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 2 * ts) {
+                for (int k = 0; k < 2 * ts; k += 2) {   // two columns per trip: their loads overlap
+                    double h0 = c.H[k * S + lane], h1 = c.H[(k + 1) * S + lane];
+                    const double g00 = Gs[k], g01 = Gs[kWave + k], g02 = Gs[2 * kWave + k];
+                    const double g10 = Gs[k + 1], g11 = Gs[kWave + k + 1], g12 = Gs[2 * kWave + k + 1];
+                    h0 = fma(gi[0], g00, h0); h0 = fma(gi[1], g01, h0); h0 = fma(gi[2], g02, h0);
+                    h1 = fma(gi[0], g10, h1); h1 = fma(gi[1], g11, h1); h1 = fma(gi[2], g12, h1);
+                    c.H[k * S + lane] = h0;
+                    c.H[(k + 1) * S + lane] = h1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        c.g = c.act ? gacc : 0.0;
+    }
+    const double hmax = wave::wmax(c.act ? c.H[lane * S + lane] : 0.0);
+
+    // solve
+    c.w = 0.0; c.lamU = c.lamL = c.nuU = c.nuL = 0.0;
+    if (!skip) {
+        int st = MPCX_ST_OK, it = 0;
+        wave::ipm(c, a.max_iter < kWaveIpmIters ? a.max_iter : kWaveIpmIters, true, st, it);
+        iters += it;
+        bool settled = wave::pdas(c, kWaveRounds0, hmax);
+        if (!settled) {
+            wave::ipm(c, a.max_iter, false, st, it);
+            iters += it;
+            status = st;
+            settled = wave::pdas(c, kWaveRounds1, hmax);
+        }
+        if (settled) status = MPCX_ST_OK;
+    }
+
+    // epilogue: controls by the stage's lane pair, states by a roll over the stages
+    const bool bad = status == MPCX_ST_NONFINITE || status == MPCX_ST_INFEASIBLE;
+    const double nan = __builtin_nan("");
+    const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
+    c.vec[lane] = c.act ? c.w : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    double Ju = 0.0;
+    {
+        auto controls = [&](double w0, double w1, double (&uu)[4]) {
+            if (v.eq_mode == MPCX_EQ_NONE) { uu[0] = w0; uu[1] = w1; uu[2] = 0.0; uu[3] = 0.0; }
+            else if (v.eq_mode == MPCX_EQ_FIXED_STEER) { uu[0] = w0; uu[1] = v.steer_fixed; uu[2] = w1; uu[3] = v.steer_fixed; }
+            else { uu[0] = w0; uu[1] = w1; uu[2] = w0; uu[3] = sg * w1; }
+        };
+        double uc[4], up[4];
+        controls(c.vec[2 * st_own], c.vec[2 * st_own + 1], uc);
+        const int tp = st_own > 0 ? st_own - 1 : 0;
+        controls(c.vec[2 * tp], c.vec[2 * tp + 1], up);
+        if (c.act && ch == 0) {
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                Ju = fma(v.R[r] * uc[r], uc[r], Ju);
+                if (st_own > 0) { const double d = uc[r] - up[r]; Ju = fma(v.Rd[r] * d, d, Ju); }
+                a.u_out[(b * NU + r) * T + st_own] = bad ? nan : uc[r];
+            }
+        }
+    }
+    double J = wave::wsum(Ju);
+    {
+        double x[3] = {x0[0], x0[1], x0[2]}, qg = 1.0;
+        double *xo = a.x_out + b * 3 * W;
+        if (lane < 3) xo[lane * W] = bad ? nan : (lane == 0 ? x[0] : lane == 1 ? x[1] : x[2]);
+        for (int t = 0; t < T; ++t) {
+            volatile wave::lds_double *d = dyn + 11 * t;
+            const double w0 = c.vec[2 * t], w1 = c.vec[2 * t + 1];
+            const double n0 = x[0] + d[0] * x[2] + d[2] * w0 + d[3] * w1 + d[8];
+            const double n1 = x[1] + d[1] * x[2] + d[4] * w0 + d[5] * w1 + d[9];
+            const double n2 = x[2] + d[6] * w0 + d[7] * w1 + d[10];
+            x[0] = n0; x[1] = n1; x[2] = n2;
+            const int ts = t + 1;
+            if (ts < T) qg *= v.q_growth;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double e = xr[r * W + ts] - x[r];
+                const double q = ts < T ? v.Q[r] * qg : v.Qf[r];
+                J = fma(q * e, e, J);
+            }
+            if (lane < 3) xo[lane * W + ts] = bad ? nan : (lane == 0 ? x[0] : lane == 1 ? x[1] : x[2]);
+        }
+    }
+    if (lane == 0) {
+        a.obj_out[b] = bad ? nan : J;
+        a.status_out[b] = status;
+        if (a.iters_out) a.iters_out[b] = iters;
+    }
+}
 
 template <int MODEL>
 __global__ __launch_bounds__(kWave) void k_solve_mem(SolveArgs a, double *ws, int64_t stride)
@@ -708,6 +950,24 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
         if (e != hipSuccess) return hip_fail(e, "k_solve_pair10 launch");
         return 0;
     }
+    if (v->T <= 32 && !(!a.linear_mode && v->chain > 1) && !g_force_single_lane) {
+        // one wavefront per instance: K and H of the instance in LDS
+        const size_t lds = (size_t)wave_lds_doubles(v->T) * sizeof(double);
+        static bool raised[2] = {false, false};
+        const int m = v->model == MPCX_MODEL_DIFF_DRIVE ? 0 : 1;
+        if (lds > 64 * 1024 && !raised[m]) {
+            hipError_t e = m == 0 ? hipFuncSetAttribute((const void *)k_solve_wave<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
+                                  : hipFuncSetAttribute((const void *)k_solve_wave<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
+            raised[m] = true;
+        }
+        const dim3 wgrid((unsigned)a.B), block(kWave);
+        if (m == 0) hipLaunchKernelGGL((k_solve_wave<0>), wgrid, block, lds, st, a);
+        else hipLaunchKernelGGL((k_solve_wave<1>), wgrid, block, lds, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "k_solve_wave launch");
+        return 0;
+    }
     // memory-resident path, chunked so the workspace stays bounded
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -829,6 +1089,7 @@ int64_t mpcx_workspace_bytes(const mpcx_variant *v, int64_t B)
     if (check_variant(v) != 0 || B < 0) return MPCX_E_ARG;
     if (uses_registers(v)) return 0;
     if (v->T == 10 && boxes_present(v) && v->chain <= 1 && !g_force_single_lane) return 0;   // lane-pair kernel
+    if (v->T <= 32 && v->chain <= 1 && !g_force_single_lane) return 0;                        // wave-per-instance kernel
     const int64_t chunk = B < kChunk ? ((B + kWave - 1) / kWave) * kWave : kChunk;
     return ws_doubles_per_instance(v->T) * chunk * (int64_t)sizeof(double);
 }

@@ -1,0 +1,340 @@
+// One wavefront per MPC instance, for horizons the lane-pair kernels do not cover
+// (n = 2T free controls, n <= 64, i.e. T <= 32; the reference's T = 30 runs are the case
+// in point).
+//
+// Lane i owns free control i = (stage i >> 1, channel i & 1): its value, its two box
+// constraints, the two rate constraints that tie it to control i + 2 (same channel, next
+// stage) and row i of every matrix.  Per-lane state is a handful of scalars; the matrices
+// live in LDS as A[k * S + i] = M(i, k) with an odd stride S >= n: a lane walking along its
+// own row, all lanes reading one element (broadcast) and a lane walking down a column
+// (stride S: at most a 2-way bank conflict) are all cheap, so the one array serves the
+// row-oriented factorisation and both triangular solves.
+//
+// Solver = the same scheme as the lane-pair kernel: a fixed number of interior-point
+// iterations (predictor-corrector, centring from the predictor's step lengths) to find the
+// active set, then primal-dual active-set rounds that certify the KKT conditions of the QP;
+// whatever does not settle takes a converged interior-point solve and the rounds again.
+#pragma once
+#include "mpcx_device.h"
+
+namespace mpcx {
+namespace wave {
+
+typedef __attribute__((address_space(3))) double lds_double;
+
+__device__ __forceinline__ double wsum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+    return x;
+}
+__device__ __forceinline__ double wmax(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = dmax(x, __shfl_xor(x, off, kWave));
+    return x;
+}
+// value of lane j on every lane, j wave-uniform: two v_readlane, no trip through LDS
+__device__ __forceinline__ double bcast(double x, int j)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), j), hi = __builtin_amdgcn_readlane(__double2hiint(x), j);
+    return __hiloint2double(hi, lo);
+}
+// value of lane `lane - 2` / `lane + 2` (0 where there is none)
+__device__ __forceinline__ double from_prev(double x, int lane) { const double y = __shfl_up(x, 2, kWave); return lane >= 2 ? y : 0.0; }
+__device__ __forceinline__ double from_next(double x, int lane) { const double y = __shfl_down(x, 2, kWave); return lane < kWave - 2 ? y : 0.0; }
+
+struct Ctx {
+    volatile lds_double *H;     // [n][S]: H(i, k) at H[k * S + i]
+    volatile lds_double *K;     // same layout: K, then its Cholesky factor (diagonal = 1 / L_ii)
+    volatile lds_double *vec;   // [64] broadcast buffer
+    int n, S, lane;
+    int row;                    // lane, or 0 on lanes beyond n (a valid address; never written)
+    bool act;                   // lane < n
+    bool hb, hr;                // this lane has a (finite) box / a (finite) rate constraint to lane + 2
+    double lo, hi, rr;          // its bounds
+    double g;                   // its gradient entry
+    double inv_m;               // 1 / number of inequality constraints of the instance
+    // iterate
+    double w, lamU, lamL, nuU, nuL;
+};
+
+// hw_i = g_i + sum_k H(i, k) v_k; optionally K(i, k) <- H(i, k) for k <= i on the way.
+template <bool COPY_K>
+__device__ __forceinline__ double matvec(const Ctx &c, double v)
+{
+    c.vec[c.lane] = c.act ? v : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    double acc0 = c.g, acc1 = 0.0;
+    int k = 0;
+    for (; k + 3 < c.n; k += 4) {   // loads of four columns in flight together
+        const double h0 = c.H[k * c.S + c.row], h1 = c.H[(k + 1) * c.S + c.row];
+        const double h2 = c.H[(k + 2) * c.S + c.row], h3 = c.H[(k + 3) * c.S + c.row];
+        const double v0 = c.vec[k], v1 = c.vec[k + 1], v2 = c.vec[k + 2], v3 = c.vec[k + 3];
+        if (COPY_K && c.act) {
+            c.K[k * c.S + c.row] = h0; c.K[(k + 1) * c.S + c.row] = h1;
+            c.K[(k + 2) * c.S + c.row] = h2; c.K[(k + 3) * c.S + c.row] = h3;
+        }
+        acc0 = fma(h0, v0, acc0); acc1 = fma(h1, v1, acc1);
+        acc0 = fma(h2, v2, acc0); acc1 = fma(h3, v3, acc1);
+    }
+    for (; k + 1 < c.n; k += 2) {
+        const double h0 = c.H[k * c.S + c.row], h1 = c.H[(k + 1) * c.S + c.row];
+        if (COPY_K && c.act) { c.K[k * c.S + c.row] = h0; c.K[(k + 1) * c.S + c.row] = h1; }
+        acc0 = fma(h0, c.vec[k], acc0);
+        acc1 = fma(h1, c.vec[k + 1], acc1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return acc0 + acc1;   // n is even
+}
+
+// In-place right-looking Cholesky of K (lower triangle; rows of inactive lanes are ignored).
+// K(j, j) ends up as 1 / L_jj.  Two columns per sweep of the trailing matrix (rank-2 update).
+__device__ __forceinline__ void chol(const Ctx &c)
+{
+    const int n = c.n, S = c.S, i = c.lane;
+    for (int j = 0; j < n; j += 2) {
+        // 2x2 diagonal block, on every lane
+        const double a = c.K[j * S + j], b = c.K[j * S + j + 1], d = c.K[(j + 1) * S + j + 1];
+        const double r0 = rsqrt_nr(a);
+        const double l10 = b * r0;
+        const double r1 = rsqrt_nr(fma(-l10, l10, d));
+        // panel: rows below the block
+        double le = 0.0, ld = 0.0;
+        if (i > j + 1 && i < n) {
+            le = c.K[j * S + i] * r0;
+            ld = fma(-le, l10, c.K[(j + 1) * S + i]) * r1;
+            c.K[j * S + i] = le;
+            c.K[(j + 1) * S + i] = ld;
+        }
+        if (i == j) c.K[j * S + j] = r0;
+        if (i == j + 1) { c.K[j * S + j + 1] = l10; c.K[(j + 1) * S + j + 1] = r1; }
+        __builtin_amdgcn_wave_barrier();
+        // trailing update: K(i, k) -= le_i le_k + ld_i ld_k for j + 1 < k <= i
+        int k = j + 2;
+        for (; k + 3 < n; k += 4) {   // four columns per trip: their loads are in flight together
+            double lek[4], ldk[4], kv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { lek[q] = c.K[j * S + k + q]; ldk[q] = c.K[(j + 1) * S + k + q]; }   // broadcast reads
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kv[q] = (i >= k + q && i < n) ? c.K[(k + q) * S + i] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i >= k + q && i < n) c.K[(k + q) * S + i] = fma(-le, lek[q], fma(-ld, ldk[q], kv[q]));
+        }
+        for (; k < n; ++k) {
+            const double lek = c.K[j * S + k], ldk = c.K[(j + 1) * S + k];
+            if (i >= k && i < n) {
+                const double kv = c.K[k * S + i];
+                c.K[k * S + i] = fma(-le, lek, fma(-ld, ldk, kv));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// x <- K^-1 r with the factor left by chol(); every lane passes its entry and gets its entry.
+__device__ __forceinline__ double solve(const Ctx &c, double r)
+{
+    const int n = c.n, S = c.S, i = c.lane;
+    double acc = c.act ? r : 0.0;
+    const int row = c.row;
+    // forward: L y = r, column by column; the factor entries of four columns are fetched ahead
+    // of the chain of broadcasts that consumes them
+    int j = 0;
+    for (; j + 3 < n; j += 4) {
+        double dj[4], lij[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dj[q] = c.K[(j + q) * S + j + q]; lij[q] = c.K[(j + q) * S + row]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double yj = bcast(acc, j + q) * dj[q];
+            if (i == j + q) acc = yj;
+            else if (i > j + q && i < n) acc = fma(-lij[q], yj, acc);
+        }
+    }
+    for (; j < n; ++j) {
+        const double yj = bcast(acc, j) * c.K[j * S + j];
+        if (i == j) acc = yj;
+        else if (i > j && i < n) acc = fma(-c.K[j * S + row], yj, acc);
+    }
+    // backward: L' z = y, row by row of L (a column walk in the array)
+    j = n - 1;
+    for (; j >= 3; j -= 4) {
+        double dj[4], lji[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dj[q] = c.K[(j - q) * S + j - q]; lji[q] = c.K[row * S + j - q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double zj = bcast(acc, j - q) * dj[q];
+            if (i == j - q) acc = zj;
+            else if (i < j - q) acc = fma(-lji[q], zj, acc);
+        }
+    }
+    for (; j >= 0; --j) {
+        const double zj = bcast(acc, j) * c.K[j * S + j];
+        if (i == j) acc = zj;
+        else if (i < j) acc = fma(-c.K[row * S + j], zj, acc);
+    }
+    return acc;
+}
+
+// K diagonal and same-channel sub-diagonal terms: `db` on the lane's own diagonal entry, `dr`
+// for its rate constraint (touches (i, i), (i + 2, i + 2) and (i + 2, i)).
+__device__ __forceinline__ void add_terms(const Ctx &c, double db, double dr)
+{
+    const int i = c.lane, S = c.S;
+    const double dprev = from_prev(dr, i);
+    if (c.act) {
+        c.K[i * S + i] += db + dr + dprev;
+        if (i >= 2) c.K[(i - 2) * S + i] -= dprev;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// C' applied to per-constraint values: box part `tb` (upper minus lower) and rate part `tr`.
+__device__ __forceinline__ double ct_apply(const Ctx &c, double tb, double tr) { return tb + from_prev(tr, c.lane) - tr; }
+
+// Predictor-corrector interior point (see pair kernels for the formulas).  `fixed`: exactly
+// max_iter iterations.  Status / iteration count are wave-uniform: one instance per wave.
+__device__ __forceinline__ void ipm(Ctx &c, int max_iter, bool fixed, int &status, int &iters)
+{
+    const int i = c.lane;
+    {
+        // strictly feasible start: every stage at the middle of its channel's first-stage window
+        double wc = c.hb ? 0.5 * (c.lo + c.hi) : 0.0;     // valid on lanes 0, 1
+        wc = __shfl(wc, i & 1, kWave);
+        c.w = c.act ? wc : 0.0;
+        c.lamU = c.hb ? kMu0 * rcp_nr(dmax(c.hi - wc, kSlackMin)) : 0.0;
+        c.lamL = c.hb ? kMu0 * rcp_nr(dmax(wc - c.lo, kSlackMin)) : 0.0;
+        const double l0 = c.hr ? kMu0 * rcp_nr(c.rr) : 0.0;
+        c.nuU = l0; c.nuL = l0;
+    }
+    status = MPCX_ST_FAILED;
+    iters = 0;
+    for (int it = 0;; ++it) {
+        if (fixed && it >= max_iter) { iters = it; return; }
+        const double hw = matvec<true>(c, c.w);
+        // slacks, barrier terms
+        const double wn = from_next(c.w, i);
+        const double su = dmax(c.hi - c.w, kSlackMin), sl = dmax(c.w - c.lo, kSlackMin);
+        const double dv = wn - c.w;
+        const double ru = dmax(c.rr - dv, kSlackMin), rl = dmax(c.rr + dv, kSlackMin);
+        const double isu = c.hb ? rcp_raw(su) : 0.0, isl = c.hb ? rcp_raw(sl) : 0.0;
+        const double iru = c.hr ? rcp_raw(ru) : 0.0, irl = c.hr ? rcp_raw(rl) : 0.0;
+        add_terms(c, fma(c.lamU, isu, c.lamL * isl), fma(c.nuU, iru, c.nuL * irl));
+        const double ctl = ct_apply(c, c.lamU - c.lamL, c.nuU - c.nuL);
+        double musum = 0.0;
+        if (c.hb) musum = fma(su, c.lamU, sl * c.lamL);
+        if (c.hr) musum = fma(ru, c.nuU, fma(rl, c.nuL, musum));
+        const double mu = wsum(musum) * c.inv_m;
+        const double rdmax = wmax(c.act ? fabs(hw + ctl) : 0.0);
+        const double scale = dmax(1.0, wmax(c.act ? dmax(fabs(hw - c.g), dmax(fabs(c.g), fabs(ctl))) : 0.0)) + 1.0;
+        const bool conv = rdmax <= kTolD * scale && mu <= kTolMu;
+        if (conv) { status = MPCX_ST_OK; iters = it; return; }
+        if (mu < kMuFloor || it >= max_iter || !finite_d(mu + rdmax)) {
+            iters = it;
+            status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
+            return;
+        }
+        chol(c);
+        // predictor
+        const double dwa = solve(c, -hw);
+        const double dva = from_next(dwa, i) - dwa;
+        const double xu = dwa * isu, xl = -dwa * isl, yu = dva * iru, yl = -dva * irl;
+        double rp = 0.0, rdm = 1.0;
+        if (c.hb) { rp = dmax(xu, xl); rdm = dmax(1.0, dmax(1.0 - xu, 1.0 - xl)); }
+        if (c.hr) { rp = dmax(rp, dmax(yu, yl)); rdm = dmax(rdm, dmax(1.0 - yu, 1.0 - yl)); }
+        rp = wmax(rp); rdm = wmax(rdm);
+        const double apa = rp > 1.0 ? rcp_nr(rp) : 1.0, ada = rcp_nr(rdm);
+        const double back = 1.0 - dmin(apa, ada);
+        const double sm = back * back * back * mu;
+        // corrector as a correction to the predictor: K (dw - dwa) = -C' q
+        const double qu = c.hb ? fma(sm, isu, c.lamU * xu * (xu - 1.0)) : 0.0;
+        const double ql = c.hb ? fma(sm, isl, c.lamL * xl * (xl - 1.0)) : 0.0;
+        const double pu = c.hr ? fma(sm, iru, c.nuU * yu * (yu - 1.0)) : 0.0;
+        const double pl = c.hr ? fma(sm, irl, c.nuL * yl * (yl - 1.0)) : 0.0;
+        const double dw = dwa + solve(c, -ct_apply(c, qu - ql, pu - pl));
+        const double dvv = from_next(dw, i) - dw;
+        const double zu = dw * isu, zl = -dw * isl, vu = dvv * iru, vl = -dvv * irl;
+        const double dlu = fma(c.lamU, zu, qu - c.lamU), dll = fma(c.lamL, zl, ql - c.lamL);
+        const double dnu = fma(c.nuU, vu, pu - c.nuU), dnl = fma(c.nuL, vl, pl - c.nuL);
+        double rp2 = 0.0, rd2 = 0.0;
+        if (c.hb) { rp2 = dmax(zu, zl); rd2 = dmax(-dlu * rcp_raw(c.lamU), -dll * rcp_raw(c.lamL)); }
+        if (c.hr) { rp2 = dmax(rp2, dmax(vu, vl)); rd2 = dmax(rd2, dmax(-dnu * rcp_raw(c.nuU), -dnl * rcp_raw(c.nuL))); }
+        rp2 = wmax(rp2); rd2 = wmax(rd2);
+        // a factorisation that broke down leaves NaN in the step: stop at the iterate we have
+        const double chk = wsum(c.act ? dw + dlu + dll + dnu + dnl : 0.0);
+        if (!finite_d(chk)) {
+            iters = it;
+            status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
+            return;
+        }
+        const double eta = dmin(kEtaCap, dmax(0.99, 1.0 - mu));
+        const double ap = rp2 > eta ? eta * rcp_nr(rp2) : 1.0;
+        const double ad = rd2 > eta ? eta * rcp_nr(rd2) : 1.0;
+        if (c.act) c.w = fma(ap, dw, c.w);
+        c.lamU = fma(ad, dlu, c.lamU); c.lamL = fma(ad, dll, c.lamL);
+        c.nuU = fma(ad, dnu, c.nuU); c.nuL = fma(ad, dnl, c.nuL);
+    }
+}
+
+// Primal-dual active-set rounds (see pdas() of the pair kernels).  Returns true when the
+// point is certified; otherwise the controls are put back as they were.
+__device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
+{
+    const int i = c.lane;
+    const double wbak = c.w;
+    const double rho = 1e5 * hmax;
+    bool au, al, bu, bl;
+    {
+        const double dv = from_next(c.w, i) - c.w;
+        au = c.hb && c.lamU > c.hi - c.w; al = c.hb && c.lamL > c.w - c.lo;
+        bu = c.hr && c.nuU > c.rr - dv; bl = c.hr && c.nuL > c.rr + dv;
+        c.lamU = au ? c.lamU : 0.0; c.lamL = al ? c.lamL : 0.0;
+        c.nuU = bu ? c.nuU : 0.0; c.nuL = bl ? c.nuL : 0.0;
+    }
+    bool changed = true, accepted = false;
+    for (int round = 0;; ++round) {
+        const double hw = matvec<true>(c, c.w);
+        const double dv = from_next(c.w, i) - c.w;
+        const double vu = c.w - c.hi, vl = c.lo - c.w, ru = dv - c.rr, rl = -dv - c.rr;
+        const double cu = au ? vu : 0.0, cl = al ? vl : 0.0, du = bu ? ru : 0.0, dl = bl ? rl : 0.0;
+        const double gl = hw + ct_apply(c, c.lamU - c.lamL, c.nuU - c.nuL);
+        const double ga = rho * ct_apply(c, cu - cl, du - dl);
+        double viol = 0.0, cact = dmax(dmax(fabs(cu), fabs(cl)), dmax(fabs(du), fabs(dl)));
+        double neg = dmax(dmax(-c.lamU, -c.lamL), dmax(-c.nuU, -c.nuL));
+        if (c.hb) viol = dmax(vu, vl);
+        if (c.hr) viol = dmax(viol, dmax(ru, rl));
+        add_terms(c, rho * ((au ? 1.0 : 0.0) + (al ? 1.0 : 0.0)), rho * ((bu ? 1.0 : 0.0) + (bl ? 1.0 : 0.0)));
+        const double stat = wmax(c.act ? fabs(gl) : 0.0);
+        const double scale = dmax(1.0, wmax(c.act ? dmax(fabs(c.g), fabs(hw - c.g)) : 0.0)) + 1.0;
+        viol = wmax(viol); cact = wmax(cact); neg = wmax(neg);
+        const bool fin = finite_d(wsum(c.act ? gl + ga + c.w : 0.0));   // max() drops NaN operands
+        if (!changed && fin && stat <= 1e-10 * scale && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) {
+            accepted = true;
+            break;
+        }
+        if (round >= max_rounds || !fin) break;
+        chol(c);
+        const double step = solve(c, -(gl + ga));
+        if (c.act) c.w += step;
+        const double ntol = -1e-9 * scale;
+        const double dv2 = from_next(c.w, i) - c.w;
+        const double vu2 = c.w - c.hi, vl2 = c.lo - c.w, ru2 = dv2 - c.rr, rl2 = -dv2 - c.rr;
+        const double lu = au ? fma(rho, vu2, c.lamU) : 0.0, ll = al ? fma(rho, vl2, c.lamL) : 0.0;
+        const double nu = bu ? fma(rho, ru2, c.nuU) : 0.0, nl = bl ? fma(rho, rl2, c.nuL) : 0.0;
+        const bool au2 = c.hb && ((au && lu >= ntol) || vu2 > 1e-12), al2 = c.hb && ((al && ll >= ntol) || vl2 > 1e-12);
+        const bool bu2 = c.hr && ((bu && nu >= ntol) || ru2 > 1e-12), bl2 = c.hr && ((bl && nl >= ntol) || rl2 > 1e-12);
+        const bool ch = au2 != au || al2 != al || bu2 != bu || bl2 != bl;
+        changed = __any(ch) != 0;
+        au = au2; al = al2; bu = bu2; bl = bl2;
+        c.lamU = au ? dmax(lu, 0.0) : 0.0; c.lamL = al ? dmax(ll, 0.0) : 0.0;
+        c.nuU = bu ? dmax(nu, 0.0) : 0.0; c.nuL = bl ? dmax(nl, 0.0) : 0.0;
+    }
+    if (!accepted) c.w = wbak;
+    return accepted;
+}
+
+}  // namespace wave
+}  // namespace mpcx

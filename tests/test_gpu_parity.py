@@ -1,4 +1,6 @@
 """HIP engine (through the C ABI) against the oracle and the golden vectors.  GPU only."""
+import math
+
 import numpy as np
 import pytest
 
@@ -214,8 +216,52 @@ def test_mpc_py_horizon_10_lane_pair_kernel(eng):
     compare(outl, refl)
 
 
-def test_long_horizons_memory_path(eng):
-    for name, T, B in (("mpc_py", 10, 1024), ("dsr_ackermann", 30, 512), ("diff_drive", 12, 512)):
+def test_wavefront_per_instance_kernel_edge_cases(eng):
+    """T = 16 (one wavefront per instance): warm/cold mix, non-finite and infeasible instances,
+    tiny batches, absent bounds, and the one-QP entry point."""
+    T = 16
+    B = 300
+    v, ov, x0, xref = make_problem("dsr_ackermann", B, seed=21, T=T)
+    ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
+    out = eng.solve_batch(v, x0, xref)
+    compare(out, ref)
+    hp = (np.arange(B) % 4 != 0).astype(np.uint8)
+    up = ref["u"].copy()
+    up[7, 1, 0] = 3.5           # first-step window outside the steer box -> infeasible
+    up[7, 3, 0] = -3.5
+    x0b, xrefb = x0.copy(), xref.copy()
+    x0b[11, 0] = np.nan
+    xrefb[19, 1, T] = np.inf
+    up[23, 0, 3] = np.nan
+    ref2 = orc.iterative_batch(ov, x0b, xrefb, up, hp, nthreads=8)
+    assert ref2["status"][7] == O.ST_INFEASIBLE and ref2["status"][11] == O.ST_NONFINITE
+    assert ref2["status"][19] == O.ST_NONFINITE and ref2["status"][23] == O.ST_NONFINITE
+    out2 = eng.solve_batch(v, x0b, xrefb, up, hp)
+    compare(out2, ref2)
+    for n in (1, 2, 65):
+        outn = eng.solve_batch(v, x0b[:n], xrefb[:n], up[:n], hp[:n])
+        compare(outn, {k: a[:n] for k, a in ref2.items()})
+    # a controller without rate or first-step bounds (only the box remains)
+    inf4 = (math.inf,) * 4
+    v3, ov3, _, _ = make_problem("dsr_ackermann", 1, T=T, dumax=inf4, first_step=inf4)
+    ref3 = orc.iterative_batch(ov3, x0, xref, None, None, nthreads=8)
+    compare(eng.solve_batch(v3, x0, xref), ref3)
+    # one QP at an arbitrary linearisation point
+    rng = np.random.default_rng(2)
+    uref = np.zeros((B, 4, T))
+    uref[:, 0] = rng.uniform(-0.4, 0.4, (B, T)); uref[:, 2] = uref[:, 0]
+    uref[:, 1] = rng.uniform(-0.5, 0.5, (B, T)); uref[:, 3] = -uref[:, 1]
+    xbar = orc.rollout_batch(ov, x0, uref)
+    refl = orc.linear_mpc_batch(ov, xref, xbar, x0, uref, nthreads=8)
+    compare(eng.linear_mpc_batch(v, xref, xbar, x0, uref), refl)
+
+
+def test_long_horizons(eng):
+    """Horizons beyond 5: the lane-pair kernel (10), one wavefront per instance (up to 32), and the
+    global-workspace kernel (longer, or chained)."""
+    for name, T, B in (("mpc_py", 10, 1024), ("dsr_ackermann", 30, 512), ("diff_drive", 12, 512),
+                       ("dsr_crab", 32, 256), ("dsr_ackermann", 40, 128), ("sim_ackermann", 8, 256),
+                       ("diff_drive", 1, 256), ("dsr_ackermann", 2, 256)):
         v, ov, x0, xref = make_problem(name, B, T=T)
         ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
         out = eng.solve_batch(v, x0, xref)
