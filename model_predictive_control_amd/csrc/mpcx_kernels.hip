@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 #include "mpcx.h"
 #include "mpcx_device.h"
@@ -250,8 +251,8 @@ constexpr int kWaveRounds0 = 8, kWaveRounds1 = 5;
 
 __host__ __device__ inline int wave_lds_doubles(int T)
 {
-    const int n = 2 * T, S = n | 1;
-    return 2 * n * S + kWave + 11 * T + (T + 1) + 3 * kWave;   // H, K, broadcast buffer, dynamics, yaw, G rows
+    const int n = 2 * T;
+    return n * (n + 1) + kWave + 11 * T + (T + 1);   // H and K (packed triangles), broadcast buffer, dynamics, yaw
 }
 
 template <int MODEL>
@@ -260,15 +261,18 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
     extern __shared__ double smem[];
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     const mpcx_variant &v = a.v;
-    const int T = v.T, W = T + 1, n = 2 * T, S = n | 1;
+    const int T = v.T, W = T + 1, n = 2 * T;
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
     wave::Ctx c;
+    c.n = n;
     c.H = (volatile wave::lds_double *)smem;
-    c.K = c.H + n * S;
-    c.vec = c.K + n * S;
-    volatile wave::lds_double *dyn = c.vec + kWave, *th = dyn + 11 * T, *Gs = th + (T + 1);
-    c.n = n; c.S = S; c.lane = lane; c.act = lane < n; c.row = c.act ? lane : 0;
+    c.K = c.H + c.size();
+    c.vec = c.K + c.size();
+    volatile wave::lds_double *dyn = c.vec + kWave, *th = dyn + 11 * T;
+    c.lane = lane; c.act = lane < n; c.row = c.act ? lane : 0; c.own = c.tri(c.row);
+    MPCX_STAMP_CLEAR();
+    MPCX_STAMP(0);
     const int st_own = c.act ? lane >> 1 : T - 1, ch = lane & 1;   // the lane's stage and channel
 
     const double *__restrict__ xr = a.xref + b * 3 * W;
@@ -322,6 +326,7 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
     }
     __builtin_amdgcn_wave_barrier();
 
+    MPCX_STAMP(1);
     // bounds of the lane's control
     {
         FreeBounds fb;
@@ -351,13 +356,15 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
             rdw[0] = v.Rd[0] + v.Rd[2]; rdw[1] = v.Rd[1] + v.Rd[3];
         }
         const double rwc = ch ? rw[1] : rw[0], rdc = ch ? rdw[1] : rdw[0];
+        for (int e = lane; e < c.size(); e += kWave) c.H[e] = 0.0;
+        __builtin_amdgcn_wave_barrier();
         if (c.act) {
-            for (int k = 0; k < n; ++k) c.H[k * S + lane] = 0.0;
             double d = 2.0 * rwc;
-            if (st_own > 0) { d += 2.0 * rdc; c.H[(lane - 2) * S + lane] = -2.0 * rdc; }
-            if (st_own + 1 < T) { d += 2.0 * rdc; c.H[(lane + 2) * S + lane] = -2.0 * rdc; }
-            c.H[lane * S + lane] = d;
+            if (st_own > 0) { d += 2.0 * rdc; c.H[c.tri(lane - 2) + lane] = -2.0 * rdc; }
+            if (st_own + 1 < T) d += 2.0 * rdc;
+            c.H[c.own + lane] = d;
         }
+        __builtin_amdgcn_wave_barrier();
         double p[3] = {x0[0], x0[1], x0[2]}, G[3] = {0.0, 0.0, 0.0}, gacc = 0.0, qg = 1.0;
         for (int t = 0; t < T; ++t) {
             volatile wave::lds_double *d = dyn + 11 * t;
@@ -388,27 +395,36 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
             double gi[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                Gs[r * kWave + lane] = G[r];
                 gi[r] = 2.0 * Qs[r] * G[r];
                 gacc = fma(gi[r], p[r] - xr[r * W + ts], gacc);
             }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 2 * ts) {
-                for (int k = 0; k < 2 * ts; k += 2) {   // two columns per trip: their loads overlap
-                    double h0 = c.H[k * S + lane], h1 = c.H[(k + 1) * S + lane];
-                    const double g00 = Gs[k], g01 = Gs[kWave + k], g02 = Gs[2 * kWave + k];
-                    const double g10 = Gs[k + 1], g11 = Gs[kWave + k + 1], g12 = Gs[2 * kWave + k + 1];
-                    h0 = fma(gi[0], g00, h0); h0 = fma(gi[1], g01, h0); h0 = fma(gi[2], g02, h0);
-                    h1 = fma(gi[0], g10, h1); h1 = fma(gi[1], g11, h1); h1 = fma(gi[2], g12, h1);
-                    c.H[k * S + lane] = h0;
-                    c.H[(k + 1) * S + lane] = h1;
+            // H(i, k) += sum_r gi_r G_r(k) for k <= i < 2 ts; G_r(k) from lane k's registers
+            auto cols = [&](int k, auto qn) {
+                constexpr int Q = decltype(qn)::value;
+                double h[Q];
+                int at[Q];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { at[q] = c.tri(k + q) + c.row; h[q] = c.H[at[q]]; }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    h[q] = fma(gi[0], wave::bcast(G[0], k + q), h[q]);
+                    h[q] = fma(gi[1], wave::bcast(G[1], k + q), h[q]);
+                    h[q] = fma(gi[2], wave::bcast(G[2], k + q), h[q]);
                 }
-            }
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                    if (lane >= k + q && lane < 2 * ts) c.H[at[q]] = h[q];
+            };
+            int k = 0;
+            for (; k + 7 < 2 * ts; k += 8) cols(k, std::integral_constant<int, 8>());
+            if (k + 3 < 2 * ts) { cols(k, std::integral_constant<int, 4>()); k += 4; }
+            if (k + 1 < 2 * ts) cols(k, std::integral_constant<int, 2>());
             __builtin_amdgcn_wave_barrier();
         }
         c.g = c.act ? gacc : 0.0;
     }
-    const double hmax = wave::wmax(c.act ? c.H[lane * S + lane] : 0.0);
+    const double hmax = wave::wmax(c.act ? c.H[c.own + lane] : 0.0);
+    MPCX_STAMP(2);
 
     // solve
     c.w = 0.0; c.lamU = c.lamL = c.nuU = c.nuL = 0.0;
@@ -416,7 +432,9 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
         int st = MPCX_ST_OK, it = 0;
         wave::ipm(c, a.max_iter < kWaveIpmIters ? a.max_iter : kWaveIpmIters, true, st, it);
         iters += it;
+        MPCX_STAMP(3);
         bool settled = wave::pdas(c, kWaveRounds0, hmax);
+        MPCX_STAMP(4);
         if (!settled) {
             wave::ipm(c, a.max_iter, false, st, it);
             iters += it;
@@ -425,6 +443,7 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
         }
         if (settled) status = MPCX_ST_OK;
     }
+    MPCX_STAMP(5);
 
     // epilogue: controls by the stage's lane pair, states by a roll over the stages
     const bool bad = status == MPCX_ST_NONFINITE || status == MPCX_ST_INFEASIBLE;
@@ -480,6 +499,7 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
         a.status_out[b] = status;
         if (a.iters_out) a.iters_out[b] = iters;
     }
+    MPCX_STAMP(6);
 }
 
 template <int MODEL>

@@ -5,10 +5,9 @@
 // Lane i owns free control i = (stage i >> 1, channel i & 1): its value, its two box
 // constraints, the two rate constraints that tie it to control i + 2 (same channel, next
 // stage) and row i of every matrix.  Per-lane state is a handful of scalars; the matrices
-// live in LDS as A[k * S + i] = M(i, k) with an odd stride S >= n: a lane walking along its
-// own row, all lanes reading one element (broadcast) and a lane walking down a column
-// (stride S: at most a 2-way bank conflict) are all cheap, so the one array serves the
-// row-oriented factorisation and both triangular solves.
+// (both symmetric) live in LDS as packed lower triangles, column after column, so that two of
+// them fit in under 30 KB at n = 60 and five instances share a compute unit: the kernel issues
+// one instruction stream per instance, and what it needs most is enough of them per SIMD.
 //
 // Solver = the same scheme as the lane-pair kernel: a fixed number of interior-point
 // iterations (predictor-corrector, centring from the predictor's step lengths) to find the
@@ -45,11 +44,12 @@ __device__ __forceinline__ double from_prev(double x, int lane) { const double y
 __device__ __forceinline__ double from_next(double x, int lane) { const double y = __shfl_down(x, 2, kWave); return lane < kWave - 2 ? y : 0.0; }
 
 struct Ctx {
-    volatile lds_double *H;     // [n][S]: H(i, k) at H[k * S + i]
+    volatile lds_double *H;     // packed lower triangle of H (see tri())
     volatile lds_double *K;     // same layout: K, then its Cholesky factor (diagonal = 1 / L_ii)
     volatile lds_double *vec;   // [64] broadcast buffer
-    int n, S, lane;
+    int n, lane;
     int row;                    // lane, or 0 on lanes beyond n (a valid address; never written)
+    int own;                    // tri(row): element (j, row) of the lane's own column sits at own + j
     bool act;                   // lane < n
     bool hb, hr;                // this lane has a (finite) box / a (finite) rate constraint to lane + 2
     double lo, hi, rr;          // its bounds
@@ -57,124 +57,185 @@ struct Ctx {
     double inv_m;               // 1 / number of inequality constraints of the instance
     // iterate
     double w, lamU, lamL, nuU, nuL;
+    // Element (i, k), k <= i, of a packed matrix sits at tri(k) + i: column k starts at
+    // tri(k) + k and the columns follow one another without gaps.  A lane walking along its
+    // row (k uniform) reads consecutive addresses across the wave; walking down its own
+    // column (own + j) it meets bank conflicts of a few ways at most.
+    __device__ __forceinline__ int tri(int k) const { return (k * (2 * n - 1 - k)) >> 1; }
+    __device__ __forceinline__ int size() const { return (n * (n + 1)) >> 1; }
 };
 
-// hw_i = g_i + sum_k H(i, k) v_k; optionally K(i, k) <- H(i, k) for k <= i on the way.
+// hw_i = g_i + sum_k H(i, k) v_k from the packed triangle (row walk left of the diagonal,
+// column walk below it); v_k comes from lane k's register (v_readlane).
+// COPY_K: K <- H on the way (same layout: a straight copy).
 template <bool COPY_K>
 __device__ __forceinline__ double matvec(const Ctx &c, double v)
 {
-    c.vec[c.lane] = c.act ? v : 0.0;
-    __builtin_amdgcn_wave_barrier();
-    double acc0 = c.g, acc1 = 0.0;
-    int k = 0;
-    for (; k + 3 < c.n; k += 4) {   // loads of four columns in flight together
-        const double h0 = c.H[k * c.S + c.row], h1 = c.H[(k + 1) * c.S + c.row];
-        const double h2 = c.H[(k + 2) * c.S + c.row], h3 = c.H[(k + 3) * c.S + c.row];
-        const double v0 = c.vec[k], v1 = c.vec[k + 1], v2 = c.vec[k + 2], v3 = c.vec[k + 3];
-        if (COPY_K && c.act) {
-            c.K[k * c.S + c.row] = h0; c.K[(k + 1) * c.S + c.row] = h1;
-            c.K[(k + 2) * c.S + c.row] = h2; c.K[(k + 3) * c.S + c.row] = h3;
+    v = c.act ? v : 0.0;
+    if (COPY_K) {
+        const int sz = c.size();
+        int e = c.lane;
+        for (; e + 3 * kWave < sz; e += 4 * kWave) {
+            double t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[q] = c.H[e + q * kWave];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c.K[e + q * kWave] = t[q];
         }
-        acc0 = fma(h0, v0, acc0); acc1 = fma(h1, v1, acc1);
-        acc0 = fma(h2, v2, acc0); acc1 = fma(h3, v3, acc1);
+        for (; e < sz; e += kWave) c.K[e] = c.H[e];
+    }
+    double acc0 = c.g, acc1 = 0.0;
+    int k = 0, tk = 0;          // tk = tri(k), advanced by n - 1 - k per column
+    for (; k + 7 < c.n; k += 8) {   // loads of eight columns in flight together
+        double h[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            h[q] = c.H[k + q <= c.row ? tk + c.row : c.own + k + q];
+            tk += c.n - 1 - (k + q);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q += 2) {
+            acc0 = fma(h[q], bcast(v, k + q), acc0);
+            acc1 = fma(h[q + 1], bcast(v, k + q + 1), acc1);
+        }
     }
     for (; k + 1 < c.n; k += 2) {
-        const double h0 = c.H[k * c.S + c.row], h1 = c.H[(k + 1) * c.S + c.row];
-        if (COPY_K && c.act) { c.K[k * c.S + c.row] = h0; c.K[(k + 1) * c.S + c.row] = h1; }
-        acc0 = fma(h0, c.vec[k], acc0);
-        acc1 = fma(h1, c.vec[k + 1], acc1);
+        const double h0 = c.H[k <= c.row ? tk + c.row : c.own + k];
+        tk += c.n - 1 - k;
+        const double h1 = c.H[k + 1 <= c.row ? tk + c.row : c.own + k + 1];
+        tk += c.n - 2 - k;
+        acc0 = fma(h0, bcast(v, k), acc0);
+        acc1 = fma(h1, bcast(v, k + 1), acc1);
     }
     __builtin_amdgcn_wave_barrier();
     return acc0 + acc1;   // n is even
 }
 
-// In-place right-looking Cholesky of K (lower triangle; rows of inactive lanes are ignored).
+// Q columns k .. k + Q - 1 of the trailing update K(i, c) -= le_i le_c + ld_i ld_c (c <= i):
+// the lane's own entries are read unconditionally (so the loads go out together; a lane
+// left of the diagonal reads a neighbouring column's entry and drops it), le_c / ld_c come
+// from lane c's registers.  `tk` = tri(k).
+template <int Q>
+__device__ __forceinline__ int chol_trail(const Ctx &c, int k, int tk, double le, double ld)
+{
+    double kv[Q];
+    int at[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        at[q] = tk + c.row;
+        kv[q] = c.K[at[q]];
+        tk += c.n - 1 - (k + q);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const double lek = bcast(le, k + q), ldk = bcast(ld, k + q);
+        kv[q] = fma(-le, lek, fma(-ld, ldk, kv[q]));
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+        if (c.lane >= k + q && c.act) c.K[at[q]] = kv[q];
+    return tk;
+}
+
+// In-place right-looking Cholesky of the packed K (rows of inactive lanes are ignored).
 // K(j, j) ends up as 1 / L_jj.  Two columns per sweep of the trailing matrix (rank-2 update).
 __device__ __forceinline__ void chol(const Ctx &c)
 {
-    const int n = c.n, S = c.S, i = c.lane;
+    const int n = c.n, i = c.lane;
+    int tj = 0;                              // tri(j)
     for (int j = 0; j < n; j += 2) {
-        // 2x2 diagonal block, on every lane
-        const double a = c.K[j * S + j], b = c.K[j * S + j + 1], d = c.K[(j + 1) * S + j + 1];
+        const int tj1 = tj + n - 1 - j;      // tri(j + 1)
+        // 2x2 diagonal block, on every lane; the lane's panel entries are fetched alongside
+        const double a = c.K[tj + j], b = c.K[tj + j + 1], d = c.K[tj1 + j + 1];
+        const double p0 = c.K[tj + c.row], p1 = c.K[tj1 + c.row];
         const double r0 = rsqrt_nr(a);
         const double l10 = b * r0;
         const double r1 = rsqrt_nr(fma(-l10, l10, d));
         // panel: rows below the block
-        double le = 0.0, ld = 0.0;
-        if (i > j + 1 && i < n) {
-            le = c.K[j * S + i] * r0;
-            ld = fma(-le, l10, c.K[(j + 1) * S + i]) * r1;
-            c.K[j * S + i] = le;
-            c.K[(j + 1) * S + i] = ld;
+        const bool below = i > j + 1 && c.act;
+        double le = p0 * r0;
+        double ld = fma(-le, l10, p1) * r1;
+        le = below ? le : 0.0;
+        ld = below ? ld : 0.0;
+        if (below) {
+            c.K[tj + i] = le;
+            c.K[tj1 + i] = ld;
         }
-        if (i == j) c.K[j * S + j] = r0;
-        if (i == j + 1) { c.K[j * S + j + 1] = l10; c.K[(j + 1) * S + j + 1] = r1; }
-        __builtin_amdgcn_wave_barrier();
-        // trailing update: K(i, k) -= le_i le_k + ld_i ld_k for j + 1 < k <= i
-        int k = j + 2;
-        for (; k + 3 < n; k += 4) {   // four columns per trip: their loads are in flight together
-            double lek[4], ldk[4], kv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { lek[q] = c.K[j * S + k + q]; ldk[q] = c.K[(j + 1) * S + k + q]; }   // broadcast reads
-#pragma unroll
-            for (int q = 0; q < 4; ++q) kv[q] = (i >= k + q && i < n) ? c.K[(k + q) * S + i] : 0.0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (i >= k + q && i < n) c.K[(k + q) * S + i] = fma(-le, lek[q], fma(-ld, ldk[q], kv[q]));
-        }
-        for (; k < n; ++k) {
-            const double lek = c.K[j * S + k], ldk = c.K[(j + 1) * S + k];
-            if (i >= k && i < n) {
-                const double kv = c.K[k * S + i];
-                c.K[k * S + i] = fma(-le, lek, fma(-ld, ldk, kv));
-            }
-        }
+        if (i == j) c.K[tj + j] = r0;
+        if (i == j + 1) { c.K[tj + j + 1] = l10; c.K[tj1 + j + 1] = r1; }
+        // trailing update of columns j + 2 .. n - 1 (an even count)
+        int k = j + 2, tk = tj1 + n - 2 - j;  // tri(j + 2)
+        tj = tk;
+        for (; k + 7 < n; k += 8) tk = chol_trail<8>(c, k, tk, le, ld);
+        if (k + 3 < n) { tk = chol_trail<4>(c, k, tk, le, ld); k += 4; }
+        if (k + 1 < n) chol_trail<2>(c, k, tk, le, ld);
         __builtin_amdgcn_wave_barrier();
     }
 }
 
 // x <- K^-1 r with the factor left by chol(); every lane passes its entry and gets its entry.
+// The factor entries of the next four columns are fetched while the chain of broadcasts works
+// through the current four.
 __device__ __forceinline__ double solve(const Ctx &c, double r)
 {
-    const int n = c.n, S = c.S, i = c.lane;
+    const int n = c.n, i = c.lane;
     double acc = c.act ? r : 0.0;
     const int row = c.row;
-    // forward: L y = r, column by column; the factor entries of four columns are fetched ahead
-    // of the chain of broadcasts that consumes them
-    int j = 0;
-    for (; j + 3 < n; j += 4) {
-        double dj[4], lij[4];
+    const int n4 = n & ~3;
+    double dj[4], lij[4], djn[4], lijn[4];
+    // forward: L y = r, column by column
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { dj[q] = c.K[(j + q) * S + j + q]; lij[q] = c.K[(j + q) * S + row]; }
+    for (int q = 0; q < 4; ++q) {
+        const int col = q < n ? q : 0, tc = c.tri(col);
+        dj[q] = c.K[tc + col]; lij[q] = c.K[tc + row];
+    }
+    int j = 0;
+    for (; j < n4; j += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = j + 4 + q < n ? j + 4 + q : 0, tc = c.tri(col);
+            djn[q] = c.K[tc + col]; lijn[q] = c.K[tc + row];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double yj = bcast(acc, j + q) * dj[q];
             if (i == j + q) acc = yj;
             else if (i > j + q && i < n) acc = fma(-lij[q], yj, acc);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dj[q] = djn[q]; lij[q] = lijn[q]; }
     }
-    for (; j < n; ++j) {
-        const double yj = bcast(acc, j) * c.K[j * S + j];
+    for (int q = 0; j < n; ++j, ++q) {   // n % 4 == 2: the two columns already fetched
+        const double yj = bcast(acc, j) * (q == 0 ? dj[0] : dj[1]);
         if (i == j) acc = yj;
-        else if (i > j && i < n) acc = fma(-c.K[j * S + row], yj, acc);
+        else if (i > j && i < n) acc = fma(-(q == 0 ? lij[0] : lij[1]), yj, acc);
     }
-    // backward: L' z = y, row by row of L (a column walk in the array)
+    // backward: L' z = y, row by row of L (the lane walks down its own column)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = n - 1 - q >= 0 ? n - 1 - q : 0;
+        dj[q] = c.K[c.tri(col) + col]; lij[q] = c.K[col >= row ? c.own + col : 0];
+    }
     j = n - 1;
     for (; j >= 3; j -= 4) {
-        double dj[4], lji[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { dj[q] = c.K[(j - q) * S + j - q]; lji[q] = c.K[row * S + j - q]; }
+        for (int q = 0; q < 4; ++q) {
+            const int col = j - 4 - q >= 0 ? j - 4 - q : 0;
+            djn[q] = c.K[c.tri(col) + col]; lijn[q] = c.K[col >= row ? c.own + col : 0];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double zj = bcast(acc, j - q) * dj[q];
             if (i == j - q) acc = zj;
-            else if (i < j - q) acc = fma(-lji[q], zj, acc);
+            else if (i < j - q) acc = fma(-lij[q], zj, acc);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { dj[q] = djn[q]; lij[q] = lijn[q]; }
     }
-    for (; j >= 0; --j) {
-        const double zj = bcast(acc, j) * c.K[j * S + j];
+    for (int q = 0; j >= 0; --j, ++q) {
+        const double zj = bcast(acc, j) * (q == 0 ? dj[0] : dj[1]);
         if (i == j) acc = zj;
-        else if (i < j) acc = fma(-c.K[row * S + j], zj, acc);
+        else if (i < j) acc = fma(-(q == 0 ? lij[0] : lij[1]), zj, acc);
     }
     return acc;
 }
@@ -183,11 +244,11 @@ __device__ __forceinline__ double solve(const Ctx &c, double r)
 // for its rate constraint (touches (i, i), (i + 2, i + 2) and (i + 2, i)).
 __device__ __forceinline__ void add_terms(const Ctx &c, double db, double dr)
 {
-    const int i = c.lane, S = c.S;
+    const int i = c.lane;
     const double dprev = from_prev(dr, i);
     if (c.act) {
-        c.K[i * S + i] += db + dr + dprev;
-        if (i >= 2) c.K[(i - 2) * S + i] -= dprev;
+        c.K[c.own + i] += db + dr + dprev;
+        if (i >= 2) c.K[c.tri(i - 2) + i] -= dprev;
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -316,8 +377,14 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
             break;
         }
         if (round >= max_rounds || !fin) break;
+        MPCX_STAMP(8);
         chol(c);
+        MPCX_STAMP(9);
         const double step = solve(c, -(gl + ga));
+        MPCX_STAMP(10);
+#ifdef MPCX_STAMPS
+        if (threadIdx.x == 0 && blockIdx.x < kStampWaves) g_stamps[blockIdx.x * kStampSlots + 7] += 1;
+#endif
         if (c.act) c.w += step;
         const double ntol = -1e-9 * scale;
         const double dv2 = from_next(c.w, i) - c.w;

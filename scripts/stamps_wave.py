@@ -1,0 +1,27 @@
+"""Phase timing of the wavefront-per-instance kernel from a -DMPCX_STAMPS build (MPCX_LIB points at it)."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from model_predictive_control_amd import engine, _lib
+from tests.helpers import make_problem
+name = sys.argv[1] if len(sys.argv) > 1 else "dsr_ackermann"
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+B = 65536
+v, ov, x0, xref = make_problem(name, B, T=T)
+for _ in range(2):
+    out = engine.solve_batch(v, x0, xref)
+torch.cuda.synchronize()
+lib = _lib.load()
+n = 4096
+buf = (C.c_ulonglong * (n * 16))()
+lib.mpcx_debug_stamps.restype = C.c_int
+lib.mpcx_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+assert lib.mpcx_debug_stamps(C.cast(buf, C.c_void_p), n) == n
+st = np.frombuffer(buf, dtype=np.uint64).reshape(n, 16).astype(np.int64)
+print("status", np.bincount(out["status"].cpu().numpy(), minlength=5), "iters mean", out["iters"].float().mean().item())
+ph = {"dynamics": st[:, 1] - st[:, 0], "condense": st[:, 2] - st[:, 1], "ipm0": st[:, 3] - st[:, 2], "pdas0": st[:, 4] - st[:, 3],
+      "fallback": st[:, 5] - st[:, 4], "epilogue": st[:, 6] - st[:, 5], "total": st[:, 6] - st[:, 0],
+      "last chol": st[:, 9] - st[:, 8], "last solve": st[:, 10] - st[:, 9]}
+print("active-set rounds per instance: mean", st[:, 7].mean(), "hist", np.bincount(st[:, 7].astype(int)))
+for nm, d in ph.items():
+    print(f"{nm:10s} median {np.median(d):9.0f} mean {d.mean():9.0f} cycles ")
