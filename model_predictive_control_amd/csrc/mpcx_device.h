@@ -1,11 +1,10 @@
 // Device-side building blocks of the batched iterative linear MPC engine (gfx950).
 //
-// One MPC instance = one lane.  The same templates serve two storage policies:
+// Shared by every solve kernel: the models, the bounds of the free controls, numeric helpers;
+// and the one-instance-per-lane dense solver over a storage policy
 //   RegStore<T>  every per-instance array is a local array with compile-time
 //                indices after full unrolling (VGPR/AGPR resident); the
-//                condensed Hessian and gradient sit in LDS as [element][lane];
-//   MemStore     runtime horizon; arrays live in a global workspace laid out
-//                [element][instance] so a wavefront's accesses coalesce.
+//                condensed Hessian and gradient sit in LDS as [element][lane].
 //
 // Algorithm per instance (float64 throughout):
 //   rollout yaw -> T linearisations -> eliminate states (condensed QP in the 2
@@ -360,49 +359,6 @@ struct RegStore {
     __device__ __forceinline__ aux_t &irl(int i) { return irl_[i]; }
     __device__ __forceinline__ double &theta(int t) { return theta_[t]; }
     __device__ __forceinline__ double &uref(int r, int t) { return uref_[r * T + t]; }
-};
-
-struct MemStore {
-    typedef double aux_t;
-    int T, N, NT;
-    double *base;    // workspace + slot index
-    int64_t stride;  // slots per element row
-    int oH, oK, oG, og, ow, olU, olL, onU, onL, ohw, odwa, odw, oisu, oisl, oiru, oirl, oth, ouref, total;
-    __host__ __device__ void layout(int T_)
-    {
-        T = T_; N = 2 * T_; NT = N * (N + 1) / 2;
-        int o = 0;
-        oH = o; o += NT; oK = o; o += NT; oG = o; o += 3 * N;
-        og = o; o += N; ow = o; o += N; olU = o; o += N; olL = o; o += N; onU = o; o += N; onL = o; o += N;
-        ohw = o; odwa = o; o += N; odw = o; o += N;   // hw and dwa share storage
-        oisu = o; o += N; oisl = o; o += N; oiru = o; o += N; oirl = o; o += N;
-        oth = o; o += T; ouref = o; o += 4 * T;
-        total = o;
-    }
-    __device__ __forceinline__ int horizon() const { return T; }
-    __device__ __forceinline__ static int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-    __device__ __forceinline__ double &at(int o) { return base[(int64_t)o * stride]; }
-    __device__ __forceinline__ double &Hacc(int i, int j) { return at(oH + tri(i, j)); }
-    __device__ __forceinline__ double &gacc(int i) { return at(og + i); }
-    __device__ __forceinline__ void finish_assembly() {}
-    __device__ __forceinline__ double H(int i, int j) { return at(oH + tri(i, j)); }
-    __device__ __forceinline__ double g(int i) { return at(og + i); }
-    __device__ __forceinline__ double &K(int i, int j) { return at(oK + tri(i, j)); }
-    __device__ __forceinline__ double &G(int r, int j) { return at(oG + r * N + j); }
-    __device__ __forceinline__ double &w(int i) { return at(ow + i); }
-    __device__ __forceinline__ double &lamU(int i) { return at(olU + i); }
-    __device__ __forceinline__ double &lamL(int i) { return at(olL + i); }
-    __device__ __forceinline__ double &nuU(int i) { return at(onU + i); }
-    __device__ __forceinline__ double &nuL(int i) { return at(onL + i); }
-    __device__ __forceinline__ double &hw(int i) { return at(ohw + i); }
-    __device__ __forceinline__ double &dwa(int i) { return at(odwa + i); }
-    __device__ __forceinline__ double &dw(int i) { return at(odw + i); }
-    __device__ __forceinline__ double &isu(int i) { return at(oisu + i); }
-    __device__ __forceinline__ double &isl(int i) { return at(oisl + i); }
-    __device__ __forceinline__ double &iru(int i) { return at(oiru + i); }
-    __device__ __forceinline__ double &irl(int i) { return at(oirl + i); }
-    __device__ __forceinline__ double &theta(int t) { return at(oth + t); }
-    __device__ __forceinline__ double &uref(int r, int t) { return at(ouref + r * T + t); }
 };
 
 // ------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 
 #include "mpcx.h"
 #include "mpcx_device.h"
+#include "mpcx_stage.h"
 
 namespace mpcx {
 // Diagnostic builds (-DMPCX_STAMPS) record the shader clock at phase boundaries of the pair
@@ -502,18 +503,180 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
     MPCX_STAMP(6);
 }
 
+// ------------------------------------------------------------------------------------
+// solve: one instance per lane, stage-wise (Riccati) linear algebra, arrays in a workspace
+// ------------------------------------------------------------------------------------
+constexpr int kStageIpmIters = 6;   // interior-point iterations before the active-set rounds
+constexpr int kStageRounds0 = 8, kStageRounds1 = 5;
+constexpr int64_t kWaveBatchMax = 1024;   // below this many instances the wavefront-per-instance kernel is used where it applies
+
 template <int MODEL>
-__global__ __launch_bounds__(kWave) void k_solve_mem(SolveArgs a, double *ws, int64_t stride)
+__global__ __launch_bounds__(kWave) void k_solve_stage(SolveArgs a, double *ws, int64_t stride)
 {
-    MemStore s;
-    s.layout(a.v.T);
+    constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
+    const mpcx_variant &v = a.v;
+    stagewise::Store s;
+    s.layout(v.T);
     const int64_t slot = (int64_t)blockIdx.x * kWave + threadIdx.x;
-    s.base = ws + slot;
-    s.stride = stride;
+    s.bind(ws, stride, slot);
     int64_t b = slot;
     const bool live = b < a.B;
     if (!live) b = a.B - 1;
-    run_instance<MODEL, false, true>(s, a, b, live);
+    const int T = v.T, W = T + 1;
+
+    stagewise::Problem p;
+    const double *__restrict__ xr = a.xref + b * 3 * W;
+    p.x0[0] = a.x0[b * 3]; p.x0[1] = a.x0[b * 3 + 1]; p.x0[2] = a.x0[b * 3 + 2];
+    bool finite = finite_d(p.x0[0]) && finite_d(p.x0[1]) && finite_d(p.x0[2]);
+    for (int i = 0; i < 3 * W; ++i) {
+        const double x = xr[i];
+        finite = finite && finite_d(x);
+        s.st(s.oXr + i, x);
+    }
+    const double *uin = a.uin ? a.uin + b * NU * T : nullptr;
+    const bool warm = a.linear_mode || (uin && (!a.has_prev || a.has_prev[b]));
+    const int chain = a.linear_mode ? 1 : (v.chain > 1 ? (v.chain < T ? v.chain : T) : 1);
+    // linearisation point: the incoming controls (or the cold-start constants) and the yaw
+    // predict_motion gives them (or xbar's); chained calls keep the yaw and start from column 0
+    // of the controls, the rest zero (mpc_sim.py:292-299)
+    {
+        double th = p.x0[2];
+        for (int t = 0; t < T; ++t) {
+            double u[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+                u[r] = warm ? uin[r * T + t] : v.cold_start[r];
+                finite = finite && finite_d(u[r]);
+            }
+            if (a.linear_mode) {
+                th = a.xbar[b * 3 * W + 2 * W + t];
+                for (int r = 0; r < 3; ++r) finite = finite && finite_d(a.xbar[b * 3 * W + r * W + t]);
+            }
+            s.st(s.oTheta + t, th);
+            th = th + yaw_rate<MODEL>(v, u) * v.dt;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s.st(s.oUref + r * T + t, (chain > 1 && t > 0) ? 0.0 : u[r]);
+        }
+        if (a.linear_mode)
+            for (int r = 0; r < 3; ++r) finite = finite && finite_d(a.xbar[b * 3 * W + r * W + T]);
+    }
+    int status = MPCX_ST_OK, iters = 0;
+    bool skip = !finite;
+    if (!finite) {
+        status = MPCX_ST_NONFINITE;
+        p.x0[0] = p.x0[1] = p.x0[2] = 0.0;
+    }
+    if (v.eq_mode == MPCX_EQ_NONE) {
+        p.rw[0] = v.R[0]; p.rw[1] = v.R[1]; p.rdw[0] = v.Rd[0]; p.rdw[1] = v.Rd[1];
+    } else if (v.eq_mode == MPCX_EQ_FIXED_STEER) {
+        p.rw[0] = v.R[0]; p.rw[1] = v.R[2]; p.rdw[0] = v.Rd[0]; p.rdw[1] = v.Rd[2];
+    } else {
+        p.rw[0] = v.R[0] + v.R[2]; p.rw[1] = v.R[1] + v.R[3];
+        p.rdw[0] = v.Rd[0] + v.Rd[2]; p.rdw[1] = v.Rd[1] + v.Rd[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { p.q[r] = v.Q[r]; p.qf[r] = v.Qf[r]; }
+    p.growth = v.q_growth;
+    const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
+    auto controls = [&](int t, double (&u)[4]) {
+        const double w0 = s.ld(s.oW + 2 * t), w1 = s.ld(s.oW + 2 * t + 1);
+        if (v.eq_mode == MPCX_EQ_NONE) { u[0] = w0; u[1] = w1; u[2] = 0.0; u[3] = 0.0; }
+        else if (v.eq_mode == MPCX_EQ_FIXED_STEER) { u[0] = w0; u[1] = v.steer_fixed; u[2] = w1; u[3] = v.steer_fixed; }
+        else { u[0] = w0; u[1] = w1; u[2] = w0; u[3] = sg * w1; }
+    };
+    for (int e = 0; e < 2 * T; ++e) s.st(s.oW + e, 0.0);
+
+    bool inaccurate = false;
+    for (int pass = 0; pass < chain; ++pass) {
+        if (pass > 0 && !skip) {   // column `pass` of uref <- previous answer (mpc_sim.py:296-299 after :302)
+            double u[4];
+            controls(pass, u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s.st(s.oUref + r * T + pass, u[r]);
+        }
+        // stage dynamics at the linearisation point
+        double u0[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < T; ++t) {
+            double u[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = s.ld(s.oUref + r * T + t);
+            if (t == 0) { u0[0] = u[0]; u0[1] = u[1]; u0[2] = u[2]; u0[3] = u[3]; }
+            double a02, a12, Bm[3][4], C[3], bt[3][2], ct[3], omega;
+            linearize<MODEL>(v, s.ld(s.oTheta + t), u, a02, a12, Bm, C, omega);
+            reduce_controls(v, Bm, C, bt, ct);
+            s.dyn_st(0, t, a02); s.dyn_st(1, t, a12);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { s.dyn_st(2 + 2 * r, t, bt[r][0]); s.dyn_st(3 + 2 * r, t, bt[r][1]); s.dyn_st(8 + r, t, ct[r]); }
+        }
+        free_bounds(v, u0, p.fb);
+        if (!p.fb.feasible && !skip) { skip = true; status = MPCX_ST_INFEASIBLE; }
+        stagewise::gradient_at_zero(s, p);
+        const double hmax = stagewise::hessian_scale(s, p);
+        int st = MPCX_ST_OK, it = 0;
+        const bool run = !skip;
+        stagewise::ipm(s, p, a.max_iter < kStageIpmIters ? a.max_iter : kStageIpmIters, true, run, st, it);
+        if (run) iters += it;
+        bool settled = stagewise::pdas(s, p, kStageRounds0, hmax, run);
+        const bool again = run && !settled;
+        if (__any(again)) {
+            stagewise::ipm(s, p, a.max_iter, false, again, st, it);
+            if (again) {
+                iters += it;
+                status = st;
+            }
+            if (stagewise::pdas(s, p, kStageRounds1, hmax, again)) settled = true;
+        }
+        if (run) {
+            if (settled) status = MPCX_ST_OK;
+            if (status == MPCX_ST_INACCURATE) inaccurate = true;
+            if (status == MPCX_ST_FAILED) skip = true;
+        }
+    }
+    if (status == MPCX_ST_OK && inaccurate) status = MPCX_ST_INACCURATE;
+
+    // controls, predicted states (the stage dynamics applied to the answer), objective
+    const bool bad = status == MPCX_ST_NONFINITE || status == MPCX_ST_INFEASIBLE;
+    const double nan = __builtin_nan("");
+    double J = 0.0, qg = 1.0;
+    double x[3] = {p.x0[0], p.x0[1], p.x0[2]};
+    double up[4] = {0, 0, 0, 0};
+    double *uo = a.u_out + b * NU * T, *xo = a.x_out + b * 3 * W;
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) xo[r * W] = bad ? nan : x[r];
+    }
+    for (int t = 0; t < T; ++t) {
+        double u[4];
+        controls(t, u);
+        const double w0 = s.ld(s.oW + 2 * t), w1 = s.ld(s.oW + 2 * t + 1);
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+            J = fma(v.R[r] * u[r], u[r], J);
+            if (t > 0) { const double d = u[r] - up[r]; J = fma(v.Rd[r] * d, d, J); }
+            up[r] = u[r];
+            if (live) uo[r * T + t] = bad ? nan : u[r];
+        }
+        stagewise::Dyn d;
+        stagewise::load_dyn(s, t, d);
+        const double n0 = x[0] + d.a02 * x[2] + d.b[0][0] * w0 + d.b[0][1] * w1 + s.dyn(8, t);
+        const double n1 = x[1] + d.a12 * x[2] + d.b[1][0] * w0 + d.b[1][1] * w1 + s.dyn(9, t);
+        const double n2 = x[2] + d.b[2][0] * w0 + d.b[2][1] * w1 + s.dyn(10, t);
+        x[0] = n0; x[1] = n1; x[2] = n2;
+        const int ts = t + 1;
+        if (ts < T) qg *= v.q_growth;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double e = xr[r * W + ts] - x[r];
+            const double q = ts < T ? v.Q[r] * qg : v.Qf[r];
+            J = fma(q * e, e, J);
+            if (live) xo[r * W + ts] = bad ? nan : x[r];
+        }
+    }
+    if (live) {
+        a.obj_out[b] = bad ? nan : J;
+        a.status_out[b] = status;
+        if (a.iters_out) a.iters_out[b] = iters;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -917,40 +1080,70 @@ static bool boxes_present(const mpcx_variant *v)
 // test hook: MPCX_SINGLE_LANE=1 routes T = 5 solves to the one-lane-per-instance kernel
 static const bool g_force_single_lane = [] { const char *e = getenv("MPCX_SINGLE_LANE"); return e && e[0] == '1'; }();
 
-// grow-only per-device workspace for the memory-resident path
+// grow-only per-device workspace of the stage-wise kernel
 static std::mutex g_ws_mutex;
 static double *g_ws[64] = {nullptr};
 static size_t g_ws_bytes[64] = {0};
-constexpr int64_t kChunk = 32768;   // instances per launch on the memory-resident path
 
-static int64_t ws_doubles_per_instance(int T)
+static int64_t stage_doubles_per_instance(int T)
 {
-    MemStore s;
-    s.layout(T);
-    return s.total;
+    stagewise::Store g;
+    g.layout(T);
+    return g.total;
+}
+// instances per launch of the stage-wise kernel: the launch's workspace stays below 4 GiB (its
+// rows are addressed with 32-bit offsets), and at most 262,144 instances
+static int64_t stage_chunk(int T, int64_t B)
+{
+    int64_t cap = (int64_t)(0xffffffffull / ((uint64_t)stage_doubles_per_instance(T) * sizeof(double))) / kWave * kWave;
+    if (cap > 262144) cap = 262144;
+    return B < cap ? ((B + kWave - 1) / kWave) * kWave : cap;
+}
+
+// test hook: MPCX_STAGEWISE=1 routes every horizon other than 5 and 10 to the stage-wise kernel,
+// =0 every one the wavefront-per-instance kernel can take to that kernel
+static const int g_stagewise = [] { const char *e = getenv("MPCX_STAGEWISE"); return e ? atoi(e) : -1; }();
+
+enum SolvePath { kPathPair5, kPathReg5, kPathPair10, kPathWave, kPathStage };
+
+// T = 5 with every bound present: lane-pair kernel, chained or not.  T = 10 (mpc.py) with both
+// boxes present, unchained: its T = 10 instantiation.  Other horizons: small batches of
+// unchained solves up to T = 32 go one wavefront per instance (lower latency: 64 lanes share
+// one instance), everything else one lane per instance with stage-wise linear algebra (far
+// higher throughput once the chip is filled).
+static SolvePath choose_path(const mpcx_variant *v, int64_t B, bool chained)
+{
+    if (uses_registers(v)) return g_force_single_lane ? kPathReg5 : kPathPair5;
+    if (v->T == 10 && boxes_present(v) && !chained && !g_force_single_lane) return kPathPair10;
+    const bool wave_fits = v->T <= 32 && !chained;
+    if (wave_fits && (g_stagewise >= 0 ? g_stagewise == 0 : B < kWaveBatchMax)) return kPathWave;
+    return kPathStage;
 }
 
 static int launch_solve(const SolveArgs &a, hipStream_t st)
 {
     const mpcx_variant *v = &a.v;
     if (a.B == 0) return 0;
-    if (uses_registers(v)) {
-        const dim3 grid((unsigned)((a.B + kWave - 1) / kWave)), block(kWave);
-        const bool chained = !a.linear_mode && v->chain > 1;
-        if (!g_force_single_lane) {
-            const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
-            if (v->model == MPCX_MODEL_DIFF_DRIVE) {
-                if (chained) hipLaunchKernelGGL((k_solve_pair5<0, true>), pgrid, block, 0, st, a);
-                else hipLaunchKernelGGL((k_solve_pair5<0, false>), pgrid, block, 0, st, a);
-            } else {
-                if (chained) hipLaunchKernelGGL((k_solve_pair5<1, true>), pgrid, block, 0, st, a);
-                else hipLaunchKernelGGL((k_solve_pair5<1, false>), pgrid, block, 0, st, a);
-            }
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return hip_fail(e, "k_solve_pair launch");
-            return 0;
+    const bool chained = !a.linear_mode && v->chain > 1;
+    const dim3 block(kWave);
+    const int m = v->model == MPCX_MODEL_DIFF_DRIVE ? 0 : 1;
+    switch (choose_path(v, a.B, chained)) {
+    case kPathPair5: {
+        const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
+        if (m == 0) {
+            if (chained) hipLaunchKernelGGL((k_solve_pair5<0, true>), pgrid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_solve_pair5<0, false>), pgrid, block, 0, st, a);
+        } else {
+            if (chained) hipLaunchKernelGGL((k_solve_pair5<1, true>), pgrid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_solve_pair5<1, false>), pgrid, block, 0, st, a);
         }
-        if (v->model == MPCX_MODEL_DIFF_DRIVE) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "k_solve_pair launch");
+        return 0;
+    }
+    case kPathReg5: {
+        const dim3 grid((unsigned)((a.B + kWave - 1) / kWave));
+        if (m == 0) {
             if (chained) hipLaunchKernelGGL((k_solve_reg<0, 5, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((k_solve_reg<0, 5, false>), grid, block, 0, st, a);
         } else {
@@ -961,43 +1154,35 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
         if (e != hipSuccess) return hip_fail(e, "k_solve_reg launch");
         return 0;
     }
-    if (v->T == 10 && boxes_present(v) && !(!a.linear_mode && v->chain > 1) && !g_force_single_lane) {
-        // the T = 10 instantiation of the lane-pair kernel (mpc.py's horizon)
-        const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave)), block(kWave);
-        if (v->model == MPCX_MODEL_DIFF_DRIVE) hipLaunchKernelGGL((k_solve_pair10<0, false>), pgrid, block, 0, st, a);
+    case kPathPair10: {
+        const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
+        if (m == 0) hipLaunchKernelGGL((k_solve_pair10<0, false>), pgrid, block, 0, st, a);
         else hipLaunchKernelGGL((k_solve_pair10<1, false>), pgrid, block, 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_solve_pair10 launch");
         return 0;
     }
-    if (v->T <= 32 && !(!a.linear_mode && v->chain > 1) && !g_force_single_lane) {
-        // one wavefront per instance: K and H of the instance in LDS
+    case kPathWave: {
+        // K and H of the instance in LDS
         const size_t lds = (size_t)wave_lds_doubles(v->T) * sizeof(double);
-        static bool raised[2] = {false, false};
-        const int m = v->model == MPCX_MODEL_DIFF_DRIVE ? 0 : 1;
-        if (lds > 64 * 1024 && !raised[m]) {
-            hipError_t e = m == 0 ? hipFuncSetAttribute((const void *)k_solve_wave<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
-                                  : hipFuncSetAttribute((const void *)k_solve_wave<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");
-            raised[m] = true;
-        }
-        const dim3 wgrid((unsigned)a.B), block(kWave);
+        const dim3 wgrid((unsigned)a.B);
         if (m == 0) hipLaunchKernelGGL((k_solve_wave<0>), wgrid, block, lds, st, a);
         else hipLaunchKernelGGL((k_solve_wave<1>), wgrid, block, lds, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_solve_wave launch");
         return 0;
     }
-    // memory-resident path, chunked so the workspace stays bounded
+    case kPathStage:
+        break;
+    }
+    // stage-wise kernel: per-lane arrays in a workspace, launches chunked so that it stays bounded
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
     if (dev < 0 || dev >= 64) return fail(MPCX_E_UNSUPPORTED, "device index %d", dev);
-    constexpr int NUmax = 4;
-    (void)NUmax;
     const int NU = v->nu, T = v->T, W = T + 1;
-    const int64_t chunk = a.B < kChunk ? ((a.B + kWave - 1) / kWave) * kWave : kChunk;
-    const size_t need = (size_t)ws_doubles_per_instance(T) * (size_t)chunk * sizeof(double);
+    const int64_t chunk = stage_chunk(T, a.B);
+    const size_t need = (size_t)stage_doubles_per_instance(T) * (size_t)chunk * sizeof(double);
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     if (g_ws_bytes[dev] < need) {
         if (g_ws[dev]) {
@@ -1024,13 +1209,11 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
         c.obj_out = a.obj_out + off;
         c.status_out = a.status_out + off;
         if (a.iters_out) c.iters_out = a.iters_out + off;
-        const dim3 grid((unsigned)((c.B + kWave - 1) / kWave)), block(kWave);
-        if (v->model == MPCX_MODEL_DIFF_DRIVE)
-            hipLaunchKernelGGL((k_solve_mem<0>), grid, block, 0, st, c, g_ws[dev], chunk);
-        else
-            hipLaunchKernelGGL((k_solve_mem<1>), grid, block, 0, st, c, g_ws[dev], chunk);
+        const dim3 grid((unsigned)((c.B + kWave - 1) / kWave));
+        if (m == 0) hipLaunchKernelGGL((k_solve_stage<0>), grid, block, 0, st, c, g_ws[dev], chunk);
+        else hipLaunchKernelGGL((k_solve_stage<1>), grid, block, 0, st, c, g_ws[dev], chunk);
         e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "k_solve_mem launch");
+        if (e != hipSuccess) return hip_fail(e, "k_solve_stage launch");
     }
     return 0;
 }
@@ -1107,11 +1290,8 @@ int mpcx_variant_by_name(const char *name, mpcx_variant *out)
 int64_t mpcx_workspace_bytes(const mpcx_variant *v, int64_t B)
 {
     if (check_variant(v) != 0 || B < 0) return MPCX_E_ARG;
-    if (uses_registers(v)) return 0;
-    if (v->T == 10 && boxes_present(v) && v->chain <= 1 && !g_force_single_lane) return 0;   // lane-pair kernel
-    if (v->T <= 32 && v->chain <= 1 && !g_force_single_lane) return 0;                        // wave-per-instance kernel
-    const int64_t chunk = B < kChunk ? ((B + kWave - 1) / kWave) * kWave : kChunk;
-    return ws_doubles_per_instance(v->T) * chunk * (int64_t)sizeof(double);
+    if (choose_path(v, B, v->chain > 1) != kPathStage) return 0;   // registers / LDS only
+    return stage_doubles_per_instance(v->T) * stage_chunk(v->T, B) * (int64_t)sizeof(double);
 }
 
 int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const double *xref,

@@ -63,9 +63,11 @@ def test_argument_validation_without_gpu(lib):
     v = variants.get("diff_drive")
     assert lib.mpcx_workspace_bytes(C.byref(v), 65536) == 0            # T = 5: register-resident
     v30 = variants.get("dsr_ackermann", T=30)
-    assert lib.mpcx_workspace_bytes(C.byref(v30), 1000) == 0           # T <= 32: one wavefront per instance, LDS only
+    assert lib.mpcx_workspace_bytes(C.byref(v30), 1000) == 0           # small batch, T <= 32: one wavefront per instance, LDS only
+    big = lib.mpcx_workspace_bytes(C.byref(v30), 1 << 20)
+    assert 0 < big < (1 << 32)                                         # stage-wise kernel: per-lane arrays, one launch below 4 GiB
     v40 = variants.get("dsr_ackermann", T=40)
-    assert lib.mpcx_workspace_bytes(C.byref(v40), 1000) > 0            # longer: matrices in a global workspace
+    assert lib.mpcx_workspace_bytes(C.byref(v40), 1000) > 0
     vbad = variants.get("diff_drive", T=65)
     assert lib.mpcx_solve_batch(C.byref(vbad), 1, None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.mpcx_solve_batch(C.byref(v), 4, None, None, None, None, None, None, None, None, None, None) == -1

@@ -1,4 +1,4 @@
-"""The benchmark's full sizes (65,536 dual-steer, 262,144 diff-drive, 4 x 1,048,576 mixed)
+"""The benchmark's full sizes (65,536 dual-steer at T = 5 and T = 30, 262,144 diff-drive, 4 x 1,048,576 mixed)
 through properties that do not need the oracle to finish 10^6 solves: every instance is
 certified, the returned controls satisfy the reference's constraints, the returned
 objective is the reference's cost expression at the returned point, the answer of an
@@ -44,9 +44,9 @@ def _cost(ov, xref, x, u):
     return J + (Qt[1:].T[None] * e * e).sum(axis=(1, 2))
 
 
-def _check(name, B, n_subset):
+def _check(name, B, n_subset, **overrides):
     from model_predictive_control_amd import engine
-    v, ov, x0, xref = make_problem(name, B, seed=19, n_courses=64)
+    v, ov, x0, xref = make_problem(name, B, seed=19, n_courses=64, **overrides)
     cold_col = np.asarray(ov.cold_start)[:ov.nu]
     out = engine.solve_batch(v, x0, xref)
     st = out["status"].cpu().numpy()
@@ -91,6 +91,11 @@ def test_65536_dual_steer_ackermann():
 
 def test_262144_diff_drive():
     _check("diff_drive", 262144, 4096)
+
+
+def test_65536_dual_steer_horizon_30():
+    """The reference's T = 30 runs (n = 60 unknowns per instance): stage-wise kernel."""
+    _check("dsr_ackermann", 65536, 2048, T=30)
 
 
 @pytest.mark.parametrize("name", ["sim_ackermann"])
