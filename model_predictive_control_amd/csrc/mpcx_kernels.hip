@@ -506,8 +506,14 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
 // ------------------------------------------------------------------------------------
 // solve: one instance per lane, stage-wise (Riccati) linear algebra, arrays in a workspace
 // ------------------------------------------------------------------------------------
-constexpr int kStageIpmIters = 6;   // interior-point iterations before the active-set rounds
-constexpr int kStageRounds0 = 8, kStageRounds1 = 5;
+#ifndef MPCX_STAGE_K
+#define MPCX_STAGE_K 6
+#endif
+#ifndef MPCX_STAGE_R0
+#define MPCX_STAGE_R0 8
+#endif
+constexpr int kStageIpmIters = MPCX_STAGE_K;   // interior-point iterations before the active-set rounds
+constexpr int kStageRounds0 = MPCX_STAGE_R0, kStageRounds1 = 5;
 constexpr int64_t kWaveBatchMax = 1024;   // below this many instances the wavefront-per-instance kernel is used where it applies
 
 template <int MODEL>

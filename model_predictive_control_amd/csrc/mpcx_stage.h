@@ -95,16 +95,16 @@ __device__ __forceinline__ void load_dyn(const Store &s, int t, Dyn &d)
     for (int r = 0; r < 3; ++r) { d.b[r][0] = s.dyn(2 + 2 * r, t); d.b[r][1] = s.dyn(3 + 2 * r, t); }
 }
 
-// Forward rollout of the linearised dynamics at the stored controls; leaves
-// 2 Q_{t+1} (x_{t+1} - xref_{t+1}) for the adjoint sweep.  `zero`: roll w = 0 instead.
-__device__ __forceinline__ void roll(const Store &s, const Problem &p, bool zero)
-{
-    const int T = s.T;
-    double x[3] = {p.x0[0], p.x0[1], p.x0[2]}, qg = 1.0;
-    _Pragma("nounroll") for (int t = 0; t < T; ++t) {
+// Forward rollout of the linearised dynamics, one stage per call; leaves
+// 2 Q_{t+1} (x_{t+1} - xref_{t+1}) for the adjoint sweep.
+struct Roller {
+    double x[3], qg;
+    __device__ __forceinline__ void start(const Problem &p) { x[0] = p.x0[0]; x[1] = p.x0[1]; x[2] = p.x0[2]; qg = 1.0; }
+    __device__ __forceinline__ void step(const Store &s, const Problem &p, int t, double w0, double w1)
+    {
+        const int T = s.T;
         Dyn d;
         load_dyn(s, t, d);
-        const double w0 = zero ? 0.0 : s.ld(s.oW + 2 * t), w1 = zero ? 0.0 : s.ld(s.oW + 2 * t + 1);
         const double n0 = x[0] + d.a02 * x[2] + d.b[0][0] * w0 + d.b[0][1] * w1 + s.dyn(8, t);
         const double n1 = x[1] + d.a12 * x[2] + d.b[1][0] * w0 + d.b[1][1] * w1 + s.dyn(9, t);
         const double n2 = x[2] + d.b[2][0] * w0 + d.b[2][1] * w1 + s.dyn(10, t);
@@ -117,6 +117,12 @@ __device__ __forceinline__ void roll(const Store &s, const Problem &p, bool zero
             s.st(s.oQe + r * T + t, 2.0 * q * (x[r] - s.ld(s.oXr + r * (T + 1) + ts)));
         }
     }
+};
+__device__ __forceinline__ void roll_zero(const Store &s, const Problem &p)
+{
+    Roller ro;
+    ro.start(p);
+    _Pragma("nounroll") for (int t = 0; t < s.T; ++t) ro.step(s, p, t, 0.0, 0.0);
 }
 
 // The backward sweep shared by every phase.  Going from the last stage to the first it forms
@@ -309,7 +315,7 @@ __device__ __forceinline__ void adjoint_step(const Store &s, int t, double a02n,
 __device__ __forceinline__ void gradient_at_zero(const Store &s, const Problem &p)
 {
     const int T = s.T;
-    roll(s, p, true);
+    roll_zero(s, p);
     double lam[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0;
     _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
         Dyn d;
@@ -425,13 +431,69 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
     }
     status = MPCX_ST_FAILED;
     iters = 0;
+    // step of the previous iteration, applied at the start of the next one in the same sweep
+    // that rolls the dynamics forward (and once more on the way out)
+    bool pend = false;
+    double ap = 0.0, ad = 0.0, sm = 0.0;
+    // corrector terms of one stage: q for the box of stage t, p for the rate constraint (t - 1, t)
+    auto corr = [&](const Slack &k, int t, int c, double lu, double ll, double nu, double nl, double da, double dap,
+                    double &qu, double &ql, double &pu, double &pl) {
+        const double xu = da * k.isu[c], xl = -da * k.isl[c];
+        const double dva = da - dap;
+        const double yu = dva * k.iru[c], yl = -dva * k.irl[c];
+        const bool hb = p.hb(t, c), hr = p.hr(c) && t > 0;
+        qu = hb ? fma(sm, k.isu[c], lu * xu * (xu - 1.0)) : 0.0;
+        ql = hb ? fma(sm, k.isl[c], ll * xl * (xl - 1.0)) : 0.0;
+        pu = hr ? fma(sm, k.iru[c], nu * yu * (yu - 1.0)) : 0.0;
+        pl = hr ? fma(sm, k.irl[c], nl * yl * (yl - 1.0)) : 0.0;
+    };
+    auto update_and_roll = [&](bool do_roll) {
+        const bool upd = pend && run;
+        Roller ro;
+        ro.start(p);
+        double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0}, dapv[2] = {0.0, 0.0};
+        _Pragma("nounroll") for (int t = 0; t < T; ++t) {
+            double wc[2] = {s.ld(s.oW + 2 * t), s.ld(s.oW + 2 * t + 1)}, wnew[2];
+            if (__any(upd)) {   // old controls of the previous stage are kept for the rate terms
+                Slack k;
+                slacks(p, t, wc, wpv, k);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const double da = s.ld(s.oDwa + 2 * t + c), dw = s.ld(s.oDw + 2 * t + c);
+                    const double lu = s.ld(s.oLU + 2 * t + c), ll = s.ld(s.oLL + 2 * t + c);
+                    const double nu = t > 0 ? s.ld(s.oNU + 2 * (t - 1) + c) : 0.0, nl = t > 0 ? s.ld(s.oNL + 2 * (t - 1) + c) : 0.0;
+                    double qu, ql, pu, pl;
+                    corr(k, t, c, lu, ll, nu, nl, da, dapv[c], qu, ql, pu, pl);
+                    const double dvv = dw - dpv[c];
+                    const double zu = dw * k.isu[c], zl = -dw * k.isl[c], vu = dvv * k.iru[c], vl = -dvv * k.irl[c];
+                    wnew[c] = upd ? fma(ap, dw, wc[c]) : wc[c];
+                    if (upd) {
+                        s.st(s.oW + 2 * t + c, wnew[c]);
+                        s.st(s.oLU + 2 * t + c, fma(ad, fma(lu, zu, qu - lu), lu));
+                        s.st(s.oLL + 2 * t + c, fma(ad, fma(ll, zl, ql - ll), ll));
+                        if (t > 0) {
+                            s.st(s.oNU + 2 * (t - 1) + c, fma(ad, fma(nu, vu, pu - nu), nu));
+                            s.st(s.oNL + 2 * (t - 1) + c, fma(ad, fma(nl, vl, pl - nl), nl));
+                        }
+                    }
+                    wpv[c] = wc[c];
+                    dpv[c] = dw;
+                    dapv[c] = da;
+                }
+            } else {
+                wnew[0] = wc[0]; wnew[1] = wc[1];
+            }
+            if (do_roll) ro.step(s, p, t, wnew[0], wnew[1]);
+        }
+        pend = false;
+    };
     for (int it = 0;; ++it) {
         if (fixed && it >= max_iter) {
             if (run) iters = it;
-            return;
+            break;
         }
-        if (!__any(run)) return;
-        roll(s, p, false);
+        if (!__any(run)) break;
+        update_and_roll(true);
         // backward: gradient, residuals, Riccati gains, feed-forward of the predictor (r = -hw)
         double musum = 0.0, rdmax = 0.0, scl = 0.0;
         {
@@ -495,7 +557,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                 run = false;
             }
         }
-        if (!__any(run)) return;
+        if (!__any(run)) break;
         // forward: predictor step and its step lengths
         double rp = 0.0, rdm = 1.0;
         {
@@ -519,19 +581,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         }
         const double apa = rp > 1.0 ? rcp_nr(rp) : 1.0, ada = rcp_nr(rdm);
         const double back = 1.0 - dmin(apa, ada);
-        const double sm = back * back * back * mu;
-        // corrector terms of one stage: q for the box of stage t, pq for the rate constraint (t - 1, t)
-        auto corr = [&](const Slack &k, int t, int c, double lu, double ll, double nu, double nl, double da, double dap,
-                        double &qu, double &ql, double &pu, double &pl) {
-            const double xu = da * k.isu[c], xl = -da * k.isl[c];
-            const double dva = da - dap;
-            const double yu = dva * k.iru[c], yl = -dva * k.irl[c];
-            const bool hb = p.hb(t, c), hr = p.hr(c) && t > 0;
-            qu = hb ? fma(sm, k.isu[c], lu * xu * (xu - 1.0)) : 0.0;
-            ql = hb ? fma(sm, k.isl[c], ll * xl * (xl - 1.0)) : 0.0;
-            pu = hr ? fma(sm, k.iru[c], nu * yu * (yu - 1.0)) : 0.0;
-            pl = hr ? fma(sm, k.irl[c], nl * yl * (yl - 1.0)) : 0.0;
-        };
+        if (run) sm = back * back * back * mu;
         // backward: feed-forward of the corrector, r_t = -(C' q)_t
         {
             Riccati R;
@@ -614,40 +664,13 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
             run = false;
         }
         const double eta = dmin(kEtaCap, dmax(0.99, 1.0 - mu));
-        const double ap = rp2 > eta ? eta * rcp_nr(rp2) : 1.0;
-        const double ad = rd2 > eta ? eta * rcp_nr(rd2) : 1.0;
-        // update (stage order; the old controls of the previous stage are kept for the rate terms)
-        if (__any(run)) {
-            double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0}, dapv[2] = {0.0, 0.0};
-            _Pragma("nounroll") for (int t = 0; t < T; ++t) {
-                double wc[2] = {s.ld(s.oW + 2 * t), s.ld(s.oW + 2 * t + 1)};
-                Slack k;
-                slacks(p, t, wc, wpv, k);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const double da = s.ld(s.oDwa + 2 * t + c), dw = s.ld(s.oDw + 2 * t + c);
-                    const double lu = s.ld(s.oLU + 2 * t + c), ll = s.ld(s.oLL + 2 * t + c);
-                    const double nu = t > 0 ? s.ld(s.oNU + 2 * (t - 1) + c) : 0.0, nl = t > 0 ? s.ld(s.oNL + 2 * (t - 1) + c) : 0.0;
-                    double qu, ql, pu, pl;
-                    corr(k, t, c, lu, ll, nu, nl, da, dapv[c], qu, ql, pu, pl);
-                    const double dvv = dw - dpv[c];
-                    const double zu = dw * k.isu[c], zl = -dw * k.isl[c], vu = dvv * k.iru[c], vl = -dvv * k.irl[c];
-                    if (run) {
-                        s.st(s.oW + 2 * t + c, fma(ap, dw, wc[c]));
-                        s.st(s.oLU + 2 * t + c, fma(ad, fma(lu, zu, qu - lu), lu));
-                        s.st(s.oLL + 2 * t + c, fma(ad, fma(ll, zl, ql - ll), ll));
-                        if (t > 0) {
-                            s.st(s.oNU + 2 * (t - 1) + c, fma(ad, fma(nu, vu, pu - nu), nu));
-                            s.st(s.oNL + 2 * (t - 1) + c, fma(ad, fma(nl, vl, pl - nl), nl));
-                        }
-                    }
-                    wpv[c] = wc[c];
-                    dpv[c] = dw;
-                    dapv[c] = da;
-                }
-            }
+        if (run) {
+            ap = rp2 > eta ? eta * rcp_nr(rp2) : 1.0;
+            ad = rd2 > eta ? eta * rcp_nr(rd2) : 1.0;
+            pend = true;
         }
     }
+    if (__any(pend && run)) update_and_roll(false);   // whoever continues from here rolls for itself
 }
 
 // ------------------------------------------------------------------------------------
@@ -660,13 +683,18 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
     const int T = s.T;
     const double rho = 1e5 * hmax;
     const bool ran = run;
-    // initial set: multiplier above slack
-    if (run) {
+    // initial set: multiplier above slack; the same sweep rolls the dynamics for the first round
+    if (__any(run)) {
+        Roller ro;
+        ro.start(p);
         double wpv[2] = {0.0, 0.0};
-        for (int t = 0; t < T; ++t)
+        _Pragma("nounroll") for (int t = 0; t < T; ++t) {
+            double wst[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const double wc = s.ld(s.oW + 2 * t + c);
+                wst[c] = wc;
+                if (!run) continue;
                 s.st(s.oBak + 2 * t + c, wc);
                 const double lu = s.ld(s.oLU + 2 * t + c), ll = s.ld(s.oLL + 2 * t + c);
                 const bool au = p.hb(t, c) && lu > p.hi(t, c) - wc, al = p.hb(t, c) && ll > wc - p.lo(t, c);
@@ -683,11 +711,12 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
                 }
                 wpv[c] = wc;
             }
+            ro.step(s, p, t, wst[0], wst[1]);
+        }
     }
     bool changed = true, accepted = false;
     for (int round = 0;; ++round) {
         if (!__any(run)) break;
-        roll(s, p, false);
         double stat = 0.0, scl = 0.0, viol = 0.0, cact = 0.0, neg = 0.0, fsum = 0.0;
         {
             Riccati R;
@@ -761,10 +790,14 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
         bool ch = false;
         {
             double wpn[2] = {0.0, 0.0};   // new controls of the previous stage
+            Roller ro;
+            ro.start(p);
             forward(s, [&](int t, const double (&u)[2]) {
+                double wst[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double wnew = s.ld(s.oW + 2 * t + c) + u[c];
+                    wst[c] = wnew;
                     const int setc = (int)s.ld(s.oSetB + 2 * t + c);
                     const bool au = setc & 1, al = setc & 2;
                     const double vu2 = wnew - p.hi(t, c), vl2 = p.lo(t, c) - wnew;
@@ -797,6 +830,7 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
                     }
                     wpn[c] = wnew;
                 }
+                ro.step(s, p, t, wst[0], wst[1]);   // for the next round's adjoint sweep
             });
         }
         changed = ch;
