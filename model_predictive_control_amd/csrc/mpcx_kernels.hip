@@ -517,7 +517,7 @@ constexpr int kStageRounds0 = MPCX_STAGE_R0, kStageRounds1 = 5;
 constexpr int64_t kWaveBatchMax = 1024;   // below this many instances the wavefront-per-instance kernel is used where it applies
 
 template <int MODEL>
-__global__ __launch_bounds__(kWave) void k_solve_stage(SolveArgs a, double *ws, int64_t stride)
+__global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *ws, int64_t stride)
 {
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     const mpcx_variant &v = a.v;
