@@ -110,6 +110,35 @@ def cpu_baseline(x0, xref, uprev, has_prev, seconds_target: float = 12.0):
             "single_thread_value": done1 / dt1, "single_thread_sample": f"{done1} solves, {dt1:.1f} s", "cvxpy": cvx}
 
 
+def other_configs(steps: int = 3):
+    """The survey's other single-GPU configurations, timed briefly beside the headline one
+    (warm-started from their own cold optimum, inputs resident): 262,144 diff-drive T=5,
+    65,536 mpc.py T=10, 65,536 dual-steer T=30."""
+    res = []
+    courses = workload.make_courses(64, seed=1001)
+    for name, B, T, kernel in (("diff_drive", 262144, None, "k_solve_pair5<diff-drive>"),
+                               ("mpc_py", 65536, None, "k_solve_pair10<dual-steer>"),
+                               ("dsr_ackermann", 65536, 30, "k_solve_stage<dual-steer>")):
+        v = variants.get(name, T=T) if T else variants.get(name)
+        inst = workload.make_instances(courses, B, seed=2003)
+        d_xref = torch.from_numpy(workload.reference_window(courses, inst, v.T)).cuda()
+        d_x0 = torch.from_numpy(inst["state"][:, :3].copy()).cuda()
+        out = engine.solve_batch(v, d_x0, d_xref)
+        up = out["u"].clone()
+        engine.solve_batch(v, d_x0, d_xref, up, out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            engine.solve_batch(v, d_x0, d_xref, up, out=out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ab = algorithmic_bytes(v.nu, v.T)
+        res.append({"workload": f"{name} T={v.T} batch {B}", "value": B / dt, "unit": "solves/s", "ms_per_step": dt * 1e3,
+                    "kernel": kernel, "solved_fraction": float((out["status"] <= 1).float().mean().item()),
+                    "algorithmic_GBps": ab * B / dt / 1e9})
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +146,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -192,6 +222,8 @@ def main():
                          "note": "the solve is FP64-VALU issue bound (5 interior-point iterations + ~4 active-set "
                                  "rounds, one 10x10 Cholesky each, per instance); HBM fraction reported as the task asks"},
         }
+        if not args.no_other_configs and world == 1:
+            line["other_configs"] = other_configs()
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(d_x0.cpu().numpy(), d_xref.cpu().numpy(), d_uprev.cpu().numpy(),
                                                 d_has.cpu().numpy())

@@ -14,6 +14,6 @@ timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 12
  && timeout -k 10 300 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err \
  && cat $OUT/bench.json \
  && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1 \
- && timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 \
- && timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 \
+ && timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_fetch.log 2>&1 \
+ && timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_write.log 2>&1 \
  && echo validate-done
