@@ -154,11 +154,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # one GPU per rank; MPCX_BENCH_BACKEND=gloo lets several ranks rehearse the multi-process
+    # flow on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device)
+    backend = os.environ.get("MPCX_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     B = args.batch
     v, d_x0, d_xref, d_uprev, d_has = build_inputs(rank, B)
