@@ -125,12 +125,12 @@ __device__ __forceinline__ void roll_zero(const Store &s, const Problem &p)
     _Pragma("nounroll") for (int t = 0; t < s.T; ++t) ro.step(s, p, t, 0.0, 0.0);
 }
 
-// The backward sweep shared by every phase.  Going from the last stage to the first it forms
-//   hw_t = (H w + g)_t                       (adjoint of the rollout + the input cost terms)
-//   the right-hand side r_t the caller wants (a functor of hw_t and whatever it loads),
-//   the Riccati gains of K = H + diag(db) + rate terms (dr), and the feed-forward for r.
-// Riccati value function of stage t: V_t(dx, v) = 1/2 [dx v]' P [dx v] + p' [dx v] with v the
-// previous stage's control step.
+// The backward sweeps of the interior point and of the active-set rounds have one shape: from
+// the last stage to the first they form hw_t = (H w + g)_t (adjoint of the rollout + the input
+// cost terms), the right-hand side r_t of the phase, the Riccati gains of
+// K = H + diag(box terms) + rate terms, and the feed-forward for r.
+// Value function of stage t: V_t(dx, v) = 1/2 [dx v]' P [dx v] + p' [dx v], v = the previous
+// stage's control step; P is kept as its blocks, the symmetric ones as upper triangles.
 struct Riccati {
     double xx[6];      // Pxx: 00 01 02 11 12 22
     double xu[3][2];   // Pxu
