@@ -517,14 +517,13 @@ constexpr int kStageRounds0 = MPCX_STAGE_R0, kStageRounds1 = 5;
 constexpr int64_t kWaveBatchMax = 1024;   // below this many instances the wavefront-per-instance kernel is used where it applies
 
 template <int MODEL>
-__global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *ws, int64_t stride)
+__global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *ws)
 {
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     const mpcx_variant &v = a.v;
     stagewise::Store s;
-    s.layout(v.T);
     const int64_t slot = (int64_t)blockIdx.x * kWave + threadIdx.x;
-    s.bind(ws, stride, slot);
+    s.bind(ws, v.T, blockIdx.x, threadIdx.x);
     int64_t b = slot;
     const bool live = b < a.B;
     if (!live) b = a.B - 1;
@@ -534,11 +533,12 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *w
     const double *__restrict__ xr = a.xref + b * 3 * W;
     p.x0[0] = a.x0[b * 3]; p.x0[1] = a.x0[b * 3 + 1]; p.x0[2] = a.x0[b * 3 + 2];
     bool finite = finite_d(p.x0[0]) && finite_d(p.x0[1]) && finite_d(p.x0[2]);
-    for (int i = 0; i < 3 * W; ++i) {
-        const double x = xr[i];
-        finite = finite && finite_d(x);
-        s.st(s.oXr + i, x);
-    }
+    for (int r = 0; r < 3; ++r)
+        for (int ts = 0; ts < W; ++ts) {
+            const double x = xr[r * W + ts];
+            finite = finite && finite_d(x);
+            if (ts > 0) s.st(s.f(s.fXr + r, ts - 1), x);
+        }
     const double *uin = a.uin ? a.uin + b * NU * T : nullptr;
     const bool warm = a.linear_mode || (uin && (!a.has_prev || a.has_prev[b]));
     const int chain = a.linear_mode ? 1 : (v.chain > 1 ? (v.chain < T ? v.chain : T) : 1);
@@ -558,10 +558,10 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *w
                 th = a.xbar[b * 3 * W + 2 * W + t];
                 for (int r = 0; r < 3; ++r) finite = finite && finite_d(a.xbar[b * 3 * W + r * W + t]);
             }
-            s.st(s.oTheta + t, th);
+            s.st(s.f(s.fTheta, t), th);
             th = th + yaw_rate<MODEL>(v, u) * v.dt;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s.st(s.oUref + r * T + t, (chain > 1 && t > 0) ? 0.0 : u[r]);
+            for (int r = 0; r < 4; ++r) s.st(s.f(s.fUref + r, t), (chain > 1 && t > 0) ? 0.0 : u[r]);
         }
         if (a.linear_mode)
             for (int r = 0; r < 3; ++r) finite = finite && finite_d(a.xbar[b * 3 * W + r * W + T]);
@@ -585,12 +585,12 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *w
     p.growth = v.q_growth;
     const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
     auto controls = [&](int t, double (&u)[4]) {
-        const double w0 = s.ld(s.oW + 2 * t), w1 = s.ld(s.oW + 2 * t + 1);
+        const double w0 = s.ld(s.p(s.fW, t, 0)), w1 = s.ld(s.p(s.fW, t, 1));
         if (v.eq_mode == MPCX_EQ_NONE) { u[0] = w0; u[1] = w1; u[2] = 0.0; u[3] = 0.0; }
         else if (v.eq_mode == MPCX_EQ_FIXED_STEER) { u[0] = w0; u[1] = v.steer_fixed; u[2] = w1; u[3] = v.steer_fixed; }
         else { u[0] = w0; u[1] = w1; u[2] = w0; u[3] = sg * w1; }
     };
-    for (int e = 0; e < 2 * T; ++e) s.st(s.oW + e, 0.0);
+    for (int t = 0; t < T; ++t) { s.st(s.p(s.fW, t, 0), 0.0); s.st(s.p(s.fW, t, 1), 0.0); }
 
     bool inaccurate = false;
     for (int pass = 0; pass < chain; ++pass) {
@@ -598,17 +598,17 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *w
             double u[4];
             controls(pass, u);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s.st(s.oUref + r * T + pass, u[r]);
+            for (int r = 0; r < 4; ++r) s.st(s.f(s.fUref + r, pass), u[r]);
         }
         // stage dynamics at the linearisation point
         double u0[4] = {0.0, 0.0, 0.0, 0.0};
         for (int t = 0; t < T; ++t) {
             double u[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) u[r] = s.ld(s.oUref + r * T + t);
+            for (int r = 0; r < 4; ++r) u[r] = s.ld(s.f(s.fUref + r, t));
             if (t == 0) { u0[0] = u[0]; u0[1] = u[1]; u0[2] = u[2]; u0[3] = u[3]; }
             double a02, a12, Bm[3][4], C[3], bt[3][2], ct[3], omega;
-            linearize<MODEL>(v, s.ld(s.oTheta + t), u, a02, a12, Bm, C, omega);
+            linearize<MODEL>(v, s.ld(s.f(s.fTheta, t)), u, a02, a12, Bm, C, omega);
             reduce_controls(v, Bm, C, bt, ct);
             s.dyn_st(0, t, a02); s.dyn_st(1, t, a12);
 #pragma unroll
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *w
     for (int t = 0; t < T; ++t) {
         double u[4];
         controls(t, u);
-        const double w0 = s.ld(s.oW + 2 * t), w1 = s.ld(s.oW + 2 * t + 1);
+        const double w0 = s.ld(s.p(s.fW, t, 0)), w1 = s.ld(s.p(s.fW, t, 1));
 #pragma unroll
         for (int r = 0; r < NU; ++r) {
             J = fma(v.R[r] * u[r], u[r], J);
@@ -1091,18 +1091,11 @@ static std::mutex g_ws_mutex;
 static double *g_ws[64] = {nullptr};
 static size_t g_ws_bytes[64] = {0};
 
-static int64_t stage_doubles_per_instance(int T)
+static int64_t stage_doubles_per_instance(int T) { return stagewise::Store::doubles_per_instance(T); }
+// instances per launch of the stage-wise kernel (bounds the workspace)
+static int64_t stage_chunk(int64_t B)
 {
-    stagewise::Store g;
-    g.layout(T);
-    return g.total;
-}
-// instances per launch of the stage-wise kernel: the launch's workspace stays below 4 GiB (its
-// rows are addressed with 32-bit offsets), and at most 262,144 instances
-static int64_t stage_chunk(int T, int64_t B)
-{
-    int64_t cap = (int64_t)(0xffffffffull / ((uint64_t)stage_doubles_per_instance(T) * sizeof(double))) / kWave * kWave;
-    if (cap > 262144) cap = 262144;
+    const int64_t cap = 262144;
     return B < cap ? ((B + kWave - 1) / kWave) * kWave : cap;
 }
 
@@ -1187,7 +1180,7 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
     if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
     if (dev < 0 || dev >= 64) return fail(MPCX_E_UNSUPPORTED, "device index %d", dev);
     const int NU = v->nu, T = v->T, W = T + 1;
-    const int64_t chunk = stage_chunk(T, a.B);
+    const int64_t chunk = stage_chunk(a.B);
     const size_t need = (size_t)stage_doubles_per_instance(T) * (size_t)chunk * sizeof(double);
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     if (g_ws_bytes[dev] < need) {
@@ -1216,8 +1209,8 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
         c.status_out = a.status_out + off;
         if (a.iters_out) c.iters_out = a.iters_out + off;
         const dim3 grid((unsigned)((c.B + kWave - 1) / kWave));
-        if (m == 0) hipLaunchKernelGGL((k_solve_stage<0>), grid, block, 0, st, c, g_ws[dev], chunk);
-        else hipLaunchKernelGGL((k_solve_stage<1>), grid, block, 0, st, c, g_ws[dev], chunk);
+        if (m == 0) hipLaunchKernelGGL((k_solve_stage<0>), grid, block, 0, st, c, g_ws[dev]);
+        else hipLaunchKernelGGL((k_solve_stage<1>), grid, block, 0, st, c, g_ws[dev]);
         e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_solve_stage launch");
     }
@@ -1297,7 +1290,7 @@ int64_t mpcx_workspace_bytes(const mpcx_variant *v, int64_t B)
 {
     if (check_variant(v) != 0 || B < 0) return MPCX_E_ARG;
     if (choose_path(v, B, v->chain > 1) != kPathStage) return 0;   // registers / LDS only
-    return stage_doubles_per_instance(v->T) * stage_chunk(v->T, B) * (int64_t)sizeof(double);
+    return stage_doubles_per_instance(v->T) * stage_chunk(B) * (int64_t)sizeof(double);
 }
 
 int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const double *xref,

@@ -10,8 +10,9 @@
 // sweep.  Nothing of size n^2 is ever formed.
 //
 // Per-lane arrays (the iterate, the stage dynamics, the Riccati gains) live in a global
-// workspace laid out [element][lane slot], so every access of a wavefront is one contiguous
-// 512-byte row; each pass over the stages streams them once.  The solver itself is the one the
+// workspace, one contiguous chunk per wavefront laid out [stage][field][lane]: every access of
+// a wavefront is one contiguous 512-byte row and each sweep over the stages streams through the
+// chunk in address order.  The solver itself is the one the
 // other kernels use: a fixed number of predictor-corrector interior-point iterations to find
 // the active set, primal-dual active-set rounds that certify the KKT conditions, and for
 // whatever does not settle a converged interior-point solve and the rounds again.
@@ -22,55 +23,59 @@ namespace mpcx {
 namespace stagewise {
 
 struct Store {
-    // Element o of the lane is ws[o * stride + slot]: a buffer access with the row's byte offset
-    // (uniform, a scalar register) and the lane's byte offset (one vector register for every
-    // array) -- no 64-bit address arithmetic per access.  The whole workspace of a launch
-    // stays below 4 GiB so that the row offset fits 32 bits.
+    // Layout: every wavefront owns one contiguous chunk of the workspace, [stage][field][lane]:
+    // the record of stage t holds everything indexed by t (kFields doubles per lane), so a sweep
+    // over the stages walks through the chunk front to back or back to front, each access one
+    // contiguous 512-byte row.  Addressed as buffer loads/stores: the chunk's descriptor and
+    // the row's byte offset are uniform (scalar registers), the lane's byte offset is the one
+    // vector register shared by every access -- no 64-bit address arithmetic per access.
+    enum Field {
+        fDyn = 0,        // a02 a12 b00 b01 b10 b11 b20 b21 c0 c1 c2
+        fXr = 11,        // reference of stage t + 1 (what the rollout of stage t is compared with)
+        fQe = 14,        // 2 Q_{t+1} (x_{t+1} - xref_{t+1})
+        fG = 17,         // gradient at w = 0
+        fW = 19,
+        fLU = 21, fLL = 23,
+        fNU = 25, fNL = 27,   // rate multipliers: the record of stage t holds constraint (t, t + 1)
+        fLx = 29, fLv = 35, fHi = 39,   // Riccati gains
+        fKv = 42,        // feed-forward of the current right-hand side
+        fDwa = 44, fDw = 46,
+        fBak = 48,       // controls before the active-set rounds
+        fSetB = 50,      // active-set flags of the boxes (1: upper, 2: lower)
+        fSetR = 52,      // ... of the rate constraints (t, t + 1), same coding
+        fUref = 54,      // linearisation point: controls and yaw (rewritten between chained solves)
+        fTheta = 58,
+        kFields = 59
+    };
     __amdgpu_buffer_rsrc_t rsrc;
-    uint32_t row_bytes;   // stride * 8
-    uint32_t lane_bytes;  // slot * 8
+    uint32_t lane_bytes;
     int T;
-    int oDyn, oXr, oQe, oG, oW, oLU, oLL, oNU, oNL, oLx, oLv, oHi, oKv, oDwa, oDw, oBak, oSetB, oSetR, oUref, oTheta, total;
-    __host__ __device__ void layout(int T_)
+    // rows of 512 bytes per wavefront chunk, made odd so that the chunks of consecutive wavefronts,
+    // which sweep their stages in near lockstep, start on different memory channels
+    __host__ __device__ static int64_t doubles_per_instance(int T) { return (int64_t)(kFields * T) | 1; }
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    // ws: the workspace; wave: index of this wavefront's chunk (uniform); lane: 0..63
+    __device__ __forceinline__ void bind(double *ws, int T_, int64_t wave, int lane)
     {
         T = T_;
-        int o = 0;
-        oDyn = o; o += 11 * T;        // a02 a12 b00 b01 b10 b11 b20 b21 c0 c1 c2, each [T]
-        oXr = o; o += 3 * (T + 1);    // reference window
-        oQe = o; o += 3 * T;          // 2 Q_{t+1} (x_{t+1} - xref_{t+1}) at index t
-        oG = o; o += 2 * T;           // gradient at w = 0
-        oW = o; o += 2 * T;
-        oLU = o; o += 2 * T; oLL = o; o += 2 * T;
-        oNU = o; o += 2 * T; oNL = o; o += 2 * T;   // rate multipliers: index t = constraint (t, t + 1)
-        oLx = o; o += 6 * T; oLv = o; o += 4 * T; oHi = o; o += 3 * T;   // Riccati gains
-        oKv = o; o += 2 * T;          // feed-forward of the current right-hand side
-        oDwa = o; o += 2 * T; oDw = o; o += 2 * T;
-        oBak = o; o += 2 * T;         // controls before the active-set rounds
-        oSetB = o; o += 2 * T;        // active-set flags of the boxes (1: upper, 2: lower)
-        oSetR = o; o += 2 * T;        // ... of the rate constraints (t, t + 1), same coding
-        oUref = o; o += 4 * T;        // linearisation point: controls and yaw (rewritten between chained solves)
-        oTheta = o; o += T;
-        total = o;
+        const int64_t chunk = doubles_per_instance(T) * kWave;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(ws + wave * chunk, 0, (int)(chunk * 8), 0x00020000);
+        lane_bytes = (uint32_t)lane * 8u;
     }
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    __device__ __forceinline__ void bind(double *ws, int64_t stride, int64_t slot)
-    {
-        const uint64_t bytes = (uint64_t)total * (uint64_t)stride * 8u;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)(bytes > 0xffffffffu ? 0xffffffffu : (uint32_t)bytes), 0x00020000);
-        row_bytes = (uint32_t)stride * 8u;
-        lane_bytes = (uint32_t)slot * 8u;
-    }
+    // element indices: field f of stage t; channel c of a two-channel field of stage t
+    __device__ __forceinline__ int f(int field, int t) const { return t * kFields + field; }
+    __device__ __forceinline__ int p(int field, int t, int c) const { return t * kFields + field + c; }
     __device__ __forceinline__ double ld(int o) const
     {
-        const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_bytes, (int)((uint32_t)o * row_bytes), 0);
+        const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane_bytes, o * (kWave * 8), 0);
         return __builtin_bit_cast(double, r);
     }
     __device__ __forceinline__ void st(int o, double x) const
     {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), rsrc, (int)lane_bytes, (int)((uint32_t)o * row_bytes), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, x), rsrc, (int)lane_bytes, o * (kWave * 8), 0);
     }
-    __device__ __forceinline__ double dyn(int f, int t) const { return ld(oDyn + f * T + t); }
-    __device__ __forceinline__ void dyn_st(int f, int t, double x) const { st(oDyn + f * T + t, x); }
+    __device__ __forceinline__ double dyn(int fld, int t) const { return ld(f(fDyn + fld, t)); }
+    __device__ __forceinline__ void dyn_st(int fld, int t, double x) const { st(f(fDyn + fld, t), x); }
 };
 
 // Everything about the instance that is not per stage.
@@ -114,7 +119,7 @@ struct Roller {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double q = ts < T ? p.q[r] * qg : p.qf[r];
-            s.st(s.oQe + r * T + t, 2.0 * q * (x[r] - s.ld(s.oXr + r * (T + 1) + ts)));
+            s.st(s.f(s.fQe + r, t), 2.0 * q * (x[r] - s.ld(s.f(s.fXr + r, ts - 1))));
         }
     }
 };
@@ -202,11 +207,11 @@ __device__ __forceinline__ void riccati_matrix_step(const Store &s, int t, const
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) s.st(s.oLx + (c * 3 + j) * T + t, Lx[c][j]);
-            s.st(s.oLv + (c * 2) * T + t, Lv[c][0]);
-            s.st(s.oLv + (c * 2 + 1) * T + t, Lv[c][1]);
+            for (int j = 0; j < 3; ++j) s.st(s.f(s.fLx + c * 3 + j, t), Lx[c][j]);
+            s.st(s.f(s.fLv + c * 2, t), Lv[c][0]);
+            s.st(s.f(s.fLv + c * 2 + 1, t), Lv[c][1]);
         }
-        s.st(s.oHi + t, i00); s.st(s.oHi + T + t, i01); s.st(s.oHi + 2 * T + t, i11);
+        s.st(s.f(s.fHi, t), i00); s.st(s.f(s.fHi + 1, t), i01); s.st(s.f(s.fHi + 2, t), i11);
     }
     if (t == 0) return;
     // A' Pxx A
@@ -246,8 +251,8 @@ __device__ __forceinline__ void riccati_vector_step(const Store &s, int t, const
     for (int c = 0; c < 2; ++c)
         hu[c] = fma(d.b[0][c], R.px[0], fma(d.b[1][c], R.px[1], fma(d.b[2][c], R.px[2], R.pu[c]))) - r[c];
     if (store) {
-        s.st(s.oKv + 2 * t, fma(Hi[0], hu[0], Hi[1] * hu[1]));
-        s.st(s.oKv + 2 * t + 1, fma(Hi[1], hu[0], Hi[2] * hu[1]));
+        s.st(s.p(s.fKv, t, 0), fma(Hi[0], hu[0], Hi[1] * hu[1]));
+        s.st(s.p(s.fKv, t, 1), fma(Hi[1], hu[0], Hi[2] * hu[1]));
     }
     const double p2 = fma(d.a02, R.px[0], fma(d.a12, R.px[1], R.px[2]));
     R.px[0] = R.px[0] - fma(Lx[0][0], hu[0], Lx[1][0] * hu[1]);
@@ -263,16 +268,16 @@ __device__ __forceinline__ void load_gains(const Store &s, int t, double (&Lx)[2
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) Lx[c][j] = s.ld(s.oLx + (c * 3 + j) * T + t);
-        Lv[c][0] = s.ld(s.oLv + (c * 2) * T + t);
-        Lv[c][1] = s.ld(s.oLv + (c * 2 + 1) * T + t);
+        for (int j = 0; j < 3; ++j) Lx[c][j] = s.ld(s.f(s.fLx + c * 3 + j, t));
+        Lv[c][0] = s.ld(s.f(s.fLv + c * 2, t));
+        Lv[c][1] = s.ld(s.f(s.fLv + c * 2 + 1, t));
     }
 }
 
 __device__ __forceinline__ void gains_of(const Store &s, int t, Gains &g)
 {
     load_gains(s, t, g.Lx, g.Lv);
-    g.Hi[0] = s.ld(s.oHi + t); g.Hi[1] = s.ld(s.oHi + s.T + t); g.Hi[2] = s.ld(s.oHi + 2 * s.T + t);
+    g.Hi[0] = s.ld(s.f(s.fHi, t)); g.Hi[1] = s.ld(s.f(s.fHi + 1, t)); g.Hi[2] = s.ld(s.f(s.fHi + 2, t));
 }
 
 // Forward sweep: the step dw_t = -(Lx dx_t + Lv dw_{t-1} + k_t), dx_{t+1} = A dx_t + B dw_t.
@@ -291,7 +296,7 @@ __device__ __forceinline__ void forward(const Store &s, F &&sink)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
             u[c] = -(fma(Lx[c][0], dx[0], fma(Lx[c][1], dx[1], fma(Lx[c][2], dx[2],
-                     fma(Lv[c][0], vp[0], fma(Lv[c][1], vp[1], s.ld(s.oKv + 2 * t + c)))))));
+                     fma(Lv[c][0], vp[0], fma(Lv[c][1], vp[1], s.ld(s.p(s.fKv, t, c))))))));
         const double n0 = dx[0] + d.a02 * dx[2] + d.b[0][0] * u[0] + d.b[0][1] * u[1];
         const double n1 = dx[1] + d.a12 * dx[2] + d.b[1][0] * u[0] + d.b[1][1] * u[1];
         const double n2 = dx[2] + d.b[2][0] * u[0] + d.b[2][1] * u[1];
@@ -306,9 +311,9 @@ __device__ __forceinline__ void adjoint_step(const Store &s, int t, double a02n,
 {
     const int T = s.T;
     const double l2 = fma(a02n, lam[0], fma(a12n, lam[1], lam[2]));   // a*n = 0 at the last stage
-    lam[0] = lam[0] + s.ld(s.oQe + t);
-    lam[1] = lam[1] + s.ld(s.oQe + T + t);
-    lam[2] = l2 + s.ld(s.oQe + 2 * T + t);
+    lam[0] = lam[0] + s.ld(s.f(s.fQe, t));
+    lam[1] = lam[1] + s.ld(s.f(s.fQe + 1, t));
+    lam[2] = l2 + s.ld(s.f(s.fQe + 2, t));
 }
 
 // Gradient at w = 0 (the g of the condensed problem), kept for the scale of the residual tests.
@@ -323,7 +328,7 @@ __device__ __forceinline__ void gradient_at_zero(const Store &s, const Problem &
         adjoint_step(s, t, a02n, a12n, lam);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-            s.st(s.oG + 2 * t + c, fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2])));
+            s.st(s.p(s.fG, t, c), fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2])));
         a02n = d.a02; a12n = d.a12;
     }
 }
@@ -421,12 +426,12 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const bool hb = p.hb(t, c), hr = p.hr(c) && t + 1 < T;
-                s.st(s.oW + 2 * t + c, wc[c]);
-                s.st(s.oLU + 2 * t + c, hb ? kMu0 * rcp_nr(dmax(p.hi(t, c) - wc[c], kSlackMin)) : 0.0);
-                s.st(s.oLL + 2 * t + c, hb ? kMu0 * rcp_nr(dmax(wc[c] - p.lo(t, c), kSlackMin)) : 0.0);
+                s.st(s.p(s.fW, t, c), wc[c]);
+                s.st(s.p(s.fLU, t, c), hb ? kMu0 * rcp_nr(dmax(p.hi(t, c) - wc[c], kSlackMin)) : 0.0);
+                s.st(s.p(s.fLL, t, c), hb ? kMu0 * rcp_nr(dmax(wc[c] - p.lo(t, c), kSlackMin)) : 0.0);
                 const double l0 = hr ? kMu0 * rcp_nr(p.fb.rr[c]) : 0.0;
-                s.st(s.oNU + 2 * t + c, l0);
-                s.st(s.oNL + 2 * t + c, l0);
+                s.st(s.p(s.fNU, t, c), l0);
+                s.st(s.p(s.fNL, t, c), l0);
             }
     }
     status = MPCX_ST_FAILED;
@@ -453,27 +458,27 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         ro.start(p);
         double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0}, dapv[2] = {0.0, 0.0};
         _Pragma("nounroll") for (int t = 0; t < T; ++t) {
-            double wc[2] = {s.ld(s.oW + 2 * t), s.ld(s.oW + 2 * t + 1)}, wnew[2];
+            double wc[2] = {s.ld(s.p(s.fW, t, 0)), s.ld(s.p(s.fW, t, 1))}, wnew[2];
             if (__any(upd)) {   // old controls of the previous stage are kept for the rate terms
                 Slack k;
                 slacks(p, t, wc, wpv, k);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double da = s.ld(s.oDwa + 2 * t + c), dw = s.ld(s.oDw + 2 * t + c);
-                    const double lu = s.ld(s.oLU + 2 * t + c), ll = s.ld(s.oLL + 2 * t + c);
-                    const double nu = t > 0 ? s.ld(s.oNU + 2 * (t - 1) + c) : 0.0, nl = t > 0 ? s.ld(s.oNL + 2 * (t - 1) + c) : 0.0;
+                    const double da = s.ld(s.p(s.fDwa, t, c)), dw = s.ld(s.p(s.fDw, t, c));
+                    const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
+                    const double nu = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0, nl = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
                     double qu, ql, pu, pl;
                     corr(k, t, c, lu, ll, nu, nl, da, dapv[c], qu, ql, pu, pl);
                     const double dvv = dw - dpv[c];
                     const double zu = dw * k.isu[c], zl = -dw * k.isl[c], vu = dvv * k.iru[c], vl = -dvv * k.irl[c];
                     wnew[c] = upd ? fma(ap, dw, wc[c]) : wc[c];
                     if (upd) {
-                        s.st(s.oW + 2 * t + c, wnew[c]);
-                        s.st(s.oLU + 2 * t + c, fma(ad, fma(lu, zu, qu - lu), lu));
-                        s.st(s.oLL + 2 * t + c, fma(ad, fma(ll, zl, ql - ll), ll));
+                        s.st(s.p(s.fW, t, c), wnew[c]);
+                        s.st(s.p(s.fLU, t, c), fma(ad, fma(lu, zu, qu - lu), lu));
+                        s.st(s.p(s.fLL, t, c), fma(ad, fma(ll, zl, ql - ll), ll));
                         if (t > 0) {
-                            s.st(s.oNU + 2 * (t - 1) + c, fma(ad, fma(nu, vu, pu - nu), nu));
-                            s.st(s.oNL + 2 * (t - 1) + c, fma(ad, fma(nl, vl, pl - nl), nl));
+                            s.st(s.p(s.fNU, t - 1, c), fma(ad, fma(nu, vu, pu - nu), nu));
+                            s.st(s.p(s.fNL, t - 1, c), fma(ad, fma(nl, vl, pl - nl), nl));
                         }
                     }
                     wpv[c] = wc[c];
@@ -503,7 +508,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
             double wn[2] = {0.0, 0.0}, dnun[2] = {0.0, 0.0};   // controls of stage t + 1, nuU - nuL of constraint (t, t + 1)
             double qg = 1.0;
             for (int t = 1; t < T; ++t) qg *= p.growth;        // growth^(T - 1)
-            double wc[2] = {s.ld(s.oW + 2 * (T - 1)), s.ld(s.oW + 2 * (T - 1) + 1)};
+            double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
             _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
                 Dyn d;
                 load_dyn(s, t, d);
@@ -511,9 +516,9 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                 if (t > 0) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        wp[c] = s.ld(s.oW + 2 * (t - 1) + c);
-                        nup[c] = s.ld(s.oNU + 2 * (t - 1) + c);
-                        nlp[c] = s.ld(s.oNL + 2 * (t - 1) + c);
+                        wp[c] = s.ld(s.p(s.fW, t - 1, c));
+                        nup[c] = s.ld(s.p(s.fNU, t - 1, c));
+                        nlp[c] = s.ld(s.p(s.fNL, t - 1, c));
                     }
                 }
                 Slack k;
@@ -522,14 +527,14 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                 double wr[2], we[2], wq[3], r[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double lu = s.ld(s.oLU + 2 * t + c), ll = s.ld(s.oLL + 2 * t + c);
+                    const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
                     const double hw = input_cost_grad(p, c, t, T, wp[c], wc[c], wn[c])
                                       + fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
                     const double ctl = (lu - ll) + (nup[c] - nlp[c]) - dnun[c];
                     if (p.hb(t, c)) musum = fma(k.su[c], lu, fma(k.sl[c], ll, musum));
                     if (p.hr(c) && t > 0) musum = fma(k.ru[c], nup[c], fma(k.rl[c], nlp[c], musum));
                     rdmax = dmax(rdmax, fabs(hw + ctl));
-                    const double g = s.ld(s.oG + 2 * t + c);
+                    const double g = s.ld(s.p(s.fG, t, c));
                     scl = dmax(scl, dmax(fabs(hw - g), dmax(fabs(g), fabs(ctl))));
                     wr[c] = 2.0 * p.rw[c] + fma(lu, k.isu[c], ll * k.isl[c]);
                     we[c] = t > 0 ? 2.0 * p.rdw[c] + fma(nup[c], k.iru[c], nlp[c] * k.irl[c]) : 0.0;
@@ -563,12 +568,12 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         {
             double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0};
             forward(s, [&](int t, const double (&u)[2]) {
-                double wc[2] = {s.ld(s.oW + 2 * t), s.ld(s.oW + 2 * t + 1)};
+                double wc[2] = {s.ld(s.p(s.fW, t, 0)), s.ld(s.p(s.fW, t, 1))};
                 Slack k;
                 slacks(p, t, wc, wpv, k);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    if (run) s.st(s.oDwa + 2 * t + c, u[c]);
+                    if (run) s.st(s.p(s.fDwa, t, c), u[c]);
                     const double xu = u[c] * k.isu[c], xl = -u[c] * k.isl[c];
                     const double dva = u[c] - dpv[c];
                     const double yu = dva * k.iru[c], yl = -dva * k.irl[c];
@@ -587,8 +592,8 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
             Riccati R;
             R.terminal(p.qf);
             double trn[2] = {0.0, 0.0};    // (pu - pl) of constraint (t, t + 1)
-            double wc[2] = {s.ld(s.oW + 2 * (T - 1)), s.ld(s.oW + 2 * (T - 1) + 1)};
-            double dc[2] = {s.ld(s.oDwa + 2 * (T - 1)), s.ld(s.oDwa + 2 * (T - 1) + 1)};
+            double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
+            double dc[2] = {s.ld(s.p(s.fDwa, T - 1, 0)), s.ld(s.p(s.fDwa, T - 1, 1))};
             _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
                 Dyn d;
                 load_dyn(s, t, d);
@@ -596,10 +601,10 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                 if (t > 0) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        wp[c] = s.ld(s.oW + 2 * (t - 1) + c);
-                        dp[c] = s.ld(s.oDwa + 2 * (t - 1) + c);
-                        nup[c] = s.ld(s.oNU + 2 * (t - 1) + c);
-                        nlp[c] = s.ld(s.oNL + 2 * (t - 1) + c);
+                        wp[c] = s.ld(s.p(s.fW, t - 1, c));
+                        dp[c] = s.ld(s.p(s.fDwa, t - 1, c));
+                        nup[c] = s.ld(s.p(s.fNU, t - 1, c));
+                        nlp[c] = s.ld(s.p(s.fNL, t - 1, c));
                     }
                 }
                 Slack k;
@@ -608,7 +613,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     double qu, ql, pu, pl;
-                    corr(k, t, c, s.ld(s.oLU + 2 * t + c), s.ld(s.oLL + 2 * t + c), nup[c], nlp[c], dc[c], dp[c], qu, ql, pu, pl);
+                    corr(k, t, c, s.ld(s.p(s.fLU, t, c)), s.ld(s.p(s.fLL, t, c)), nup[c], nlp[c], dc[c], dp[c], qu, ql, pu, pl);
                     r[c] = -((qu - ql) + (pu - pl) - trn[c]);
                     trn[c] = pu - pl;
                     wc[c] = wp[c];
@@ -624,16 +629,16 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         {
             double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0}, dapv[2] = {0.0, 0.0};
             forward(s, [&](int t, const double (&uc)[2]) {
-                double wc[2] = {s.ld(s.oW + 2 * t), s.ld(s.oW + 2 * t + 1)};
+                double wc[2] = {s.ld(s.p(s.fW, t, 0)), s.ld(s.p(s.fW, t, 1))};
                 Slack k;
                 slacks(p, t, wc, wpv, k);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double da = s.ld(s.oDwa + 2 * t + c);
+                    const double da = s.ld(s.p(s.fDwa, t, c));
                     const double dw = da + uc[c];
-                    if (run) s.st(s.oDw + 2 * t + c, dw);
-                    const double lu = s.ld(s.oLU + 2 * t + c), ll = s.ld(s.oLL + 2 * t + c);
-                    const double nu = t > 0 ? s.ld(s.oNU + 2 * (t - 1) + c) : 0.0, nl = t > 0 ? s.ld(s.oNL + 2 * (t - 1) + c) : 0.0;
+                    if (run) s.st(s.p(s.fDw, t, c), dw);
+                    const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
+                    const double nu = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0, nl = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
                     double qu, ql, pu, pl;
                     corr(k, t, c, lu, ll, nu, nl, da, dapv[c], qu, ql, pu, pl);
                     const double dvv = dw - dpv[c];
@@ -692,22 +697,22 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
             double wst[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const double wc = s.ld(s.oW + 2 * t + c);
+                const double wc = s.ld(s.p(s.fW, t, c));
                 wst[c] = wc;
                 if (!run) continue;
-                s.st(s.oBak + 2 * t + c, wc);
-                const double lu = s.ld(s.oLU + 2 * t + c), ll = s.ld(s.oLL + 2 * t + c);
+                s.st(s.p(s.fBak, t, c), wc);
+                const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
                 const bool au = p.hb(t, c) && lu > p.hi(t, c) - wc, al = p.hb(t, c) && ll > wc - p.lo(t, c);
-                s.st(s.oLU + 2 * t + c, au ? lu : 0.0);
-                s.st(s.oLL + 2 * t + c, al ? ll : 0.0);
-                s.st(s.oSetB + 2 * t + c, (double)((au ? 1 : 0) | (al ? 2 : 0)));
+                s.st(s.p(s.fLU, t, c), au ? lu : 0.0);
+                s.st(s.p(s.fLL, t, c), al ? ll : 0.0);
+                s.st(s.p(s.fSetB, t, c), (double)((au ? 1 : 0) | (al ? 2 : 0)));
                 if (t > 0) {
                     const double dv = wc - wpv[c];
-                    const double nu = s.ld(s.oNU + 2 * (t - 1) + c), nl = s.ld(s.oNL + 2 * (t - 1) + c);
+                    const double nu = s.ld(s.p(s.fNU, t - 1, c)), nl = s.ld(s.p(s.fNL, t - 1, c));
                     const bool bu = p.hr(c) && nu > p.fb.rr[c] - dv, bl = p.hr(c) && nl > p.fb.rr[c] + dv;
-                    s.st(s.oNU + 2 * (t - 1) + c, bu ? nu : 0.0);
-                    s.st(s.oNL + 2 * (t - 1) + c, bl ? nl : 0.0);
-                    s.st(s.oSetR + 2 * (t - 1) + c, (double)((bu ? 1 : 0) | (bl ? 2 : 0)));
+                    s.st(s.p(s.fNU, t - 1, c), bu ? nu : 0.0);
+                    s.st(s.p(s.fNL, t - 1, c), bl ? nl : 0.0);
+                    s.st(s.p(s.fSetR, t - 1, c), (double)((bu ? 1 : 0) | (bl ? 2 : 0)));
                 }
                 wpv[c] = wc;
             }
@@ -725,7 +730,7 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
             double wn[2] = {0.0, 0.0}, dnun[2] = {0.0, 0.0}, trn[2] = {0.0, 0.0};
             double qg = 1.0;
             for (int t = 1; t < T; ++t) qg *= p.growth;
-            double wc[2] = {s.ld(s.oW + 2 * (T - 1)), s.ld(s.oW + 2 * (T - 1) + 1)};
+            double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
             _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
                 Dyn d;
                 load_dyn(s, t, d);
@@ -736,14 +741,14 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
                     double wp = 0.0, nup = 0.0, nlp = 0.0;
                     int setp = 0;
                     if (t > 0) {
-                        wp = s.ld(s.oW + 2 * (t - 1) + c);
-                        nup = s.ld(s.oNU + 2 * (t - 1) + c);
-                        nlp = s.ld(s.oNL + 2 * (t - 1) + c);
-                        setp = (int)s.ld(s.oSetR + 2 * (t - 1) + c);
+                        wp = s.ld(s.p(s.fW, t - 1, c));
+                        nup = s.ld(s.p(s.fNU, t - 1, c));
+                        nlp = s.ld(s.p(s.fNL, t - 1, c));
+                        setp = (int)s.ld(s.p(s.fSetR, t - 1, c));
                     }
-                    const int setc = (int)s.ld(s.oSetB + 2 * t + c);
+                    const int setc = (int)s.ld(s.p(s.fSetB, t, c));
                     const bool au = setc & 1, al = setc & 2, bu = setp & 1, bl = setp & 2;
-                    const double lu = s.ld(s.oLU + 2 * t + c), ll = s.ld(s.oLL + 2 * t + c);
+                    const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
                     const double dv = wc[c] - wp;
                     const double vu = wc[c] - p.hi(t, c), vl = p.lo(t, c) - wc[c];
                     const double ru = dv - p.fb.rr[c], rl = -dv - p.fb.rr[c];
@@ -757,7 +762,7 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
                     cact = dmax(cact, dmax(dmax(fabs(cu), fabs(cl)), dmax(fabs(du), fabs(dl))));
                     neg = dmax(neg, dmax(dmax(-lu, -ll), dmax(-nup, -nlp)));
                     stat = dmax(stat, fabs(gl));
-                    const double g = s.ld(s.oG + 2 * t + c);
+                    const double g = s.ld(s.p(s.fG, t, c));
                     scl = dmax(scl, dmax(fabs(g), fabs(hw - g)));
                     fsum += gl + ga + wc[c];
                     wr[c] = 2.0 * p.rw[c] + rho * ((au ? 1.0 : 0.0) + (al ? 1.0 : 0.0));
@@ -796,36 +801,36 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
                 double wst[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double wnew = s.ld(s.oW + 2 * t + c) + u[c];
+                    const double wnew = s.ld(s.p(s.fW, t, c)) + u[c];
                     wst[c] = wnew;
-                    const int setc = (int)s.ld(s.oSetB + 2 * t + c);
+                    const int setc = (int)s.ld(s.p(s.fSetB, t, c));
                     const bool au = setc & 1, al = setc & 2;
                     const double vu2 = wnew - p.hi(t, c), vl2 = p.lo(t, c) - wnew;
-                    const double lu = au ? fma(rho, vu2, s.ld(s.oLU + 2 * t + c)) : 0.0;
-                    const double ll = al ? fma(rho, vl2, s.ld(s.oLL + 2 * t + c)) : 0.0;
+                    const double lu = au ? fma(rho, vu2, s.ld(s.p(s.fLU, t, c))) : 0.0;
+                    const double ll = al ? fma(rho, vl2, s.ld(s.p(s.fLL, t, c))) : 0.0;
                     const bool au2 = p.hb(t, c) && ((au && lu >= ntol) || vu2 > 1e-12);
                     const bool al2 = p.hb(t, c) && ((al && ll >= ntol) || vl2 > 1e-12);
                     ch = ch || au2 != au || al2 != al;
                     if (run) {
-                        s.st(s.oW + 2 * t + c, wnew);
-                        s.st(s.oLU + 2 * t + c, au2 ? dmax(lu, 0.0) : 0.0);
-                        s.st(s.oLL + 2 * t + c, al2 ? dmax(ll, 0.0) : 0.0);
-                        s.st(s.oSetB + 2 * t + c, (double)((au2 ? 1 : 0) | (al2 ? 2 : 0)));
+                        s.st(s.p(s.fW, t, c), wnew);
+                        s.st(s.p(s.fLU, t, c), au2 ? dmax(lu, 0.0) : 0.0);
+                        s.st(s.p(s.fLL, t, c), al2 ? dmax(ll, 0.0) : 0.0);
+                        s.st(s.p(s.fSetB, t, c), (double)((au2 ? 1 : 0) | (al2 ? 2 : 0)));
                     }
                     if (t > 0) {
-                        const int setp = (int)s.ld(s.oSetR + 2 * (t - 1) + c);
+                        const int setp = (int)s.ld(s.p(s.fSetR, t - 1, c));
                         const bool bu = setp & 1, bl = setp & 2;
                         const double dv2 = wnew - wpn[c];
                         const double ru2 = dv2 - p.fb.rr[c], rl2 = -dv2 - p.fb.rr[c];
-                        const double nu = bu ? fma(rho, ru2, s.ld(s.oNU + 2 * (t - 1) + c)) : 0.0;
-                        const double nl = bl ? fma(rho, rl2, s.ld(s.oNL + 2 * (t - 1) + c)) : 0.0;
+                        const double nu = bu ? fma(rho, ru2, s.ld(s.p(s.fNU, t - 1, c))) : 0.0;
+                        const double nl = bl ? fma(rho, rl2, s.ld(s.p(s.fNL, t - 1, c))) : 0.0;
                         const bool bu2 = p.hr(c) && ((bu && nu >= ntol) || ru2 > 1e-12);
                         const bool bl2 = p.hr(c) && ((bl && nl >= ntol) || rl2 > 1e-12);
                         ch = ch || bu2 != bu || bl2 != bl;
                         if (run) {
-                            s.st(s.oNU + 2 * (t - 1) + c, bu2 ? dmax(nu, 0.0) : 0.0);
-                            s.st(s.oNL + 2 * (t - 1) + c, bl2 ? dmax(nl, 0.0) : 0.0);
-                            s.st(s.oSetR + 2 * (t - 1) + c, (double)((bu2 ? 1 : 0) | (bl2 ? 2 : 0)));
+                            s.st(s.p(s.fNU, t - 1, c), bu2 ? dmax(nu, 0.0) : 0.0);
+                            s.st(s.p(s.fNL, t - 1, c), bl2 ? dmax(nl, 0.0) : 0.0);
+                            s.st(s.p(s.fSetR, t - 1, c), (double)((bu2 ? 1 : 0) | (bl2 ? 2 : 0)));
                         }
                     }
                     wpn[c] = wnew;
@@ -836,7 +841,10 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
         changed = ch;
     }
     if (ran && !accepted)
-        for (int e = 0; e < 2 * T; ++e) s.st(s.oW + e, s.ld(s.oBak + e));
+        for (int t = 0; t < T; ++t) {
+            s.st(s.p(s.fW, t, 0), s.ld(s.p(s.fBak, t, 0)));
+            s.st(s.p(s.fW, t, 1), s.ld(s.p(s.fBak, t, 1)));
+        }
     return accepted;
 }
 
