@@ -273,7 +273,7 @@ def test_long_horizons(eng):
 
 
 def test_headline_batch_full_size(eng):
-    """BASELINE's 65,536-instance T=5 general-bicycle batch, checked instance by instance."""
+    """The headline 65,536-instance T=5 general-bicycle batch, checked instance by instance."""
     B = 65536
     v, ov, x0, xref = make_problem("dsr_ackermann", B, seed=2003, n_courses=64)
     ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=16)
