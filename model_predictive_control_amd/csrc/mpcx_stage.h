@@ -84,6 +84,7 @@ struct Problem {
     double rw[2], rdw[2];      // cost on the free controls and on their differences
     double q[3], qf[3], growth;
     double x0[3];
+    double mu0;                // initial complementarity
     __device__ __forceinline__ bool hb(int t, int c) const { return t == 0 ? fb.box0[c] : fb.box[c]; }
     __device__ __forceinline__ double lo(int t, int c) const { return t == 0 ? fb.lo0[c] : -fb.b[c]; }
     __device__ __forceinline__ double hi(int t, int c) const { return t == 0 ? fb.hi0[c] : fb.b[c]; }
@@ -317,8 +318,9 @@ __device__ __forceinline__ void adjoint_step(const Store &s, int t, double a02n,
 }
 
 // Gradient at w = 0 (the g of the condensed problem), kept for the scale of the residual tests.
-__device__ __forceinline__ void gradient_at_zero(const Store &s, const Problem &p)
+__device__ __forceinline__ double gradient_at_zero(const Store &s, const Problem &p)
 {
+    double gmax = 0.0;
     const int T = s.T;
     roll_zero(s, p);
     double lam[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0;
@@ -327,10 +329,14 @@ __device__ __forceinline__ void gradient_at_zero(const Store &s, const Problem &
         load_dyn(s, t, d);
         adjoint_step(s, t, a02n, a12n, lam);
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-            s.st(s.p(s.fG, t, c), fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2])));
+        for (int c = 0; c < 2; ++c) {
+            const double g = fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
+            gmax = dmax(gmax, fabs(g));
+            s.st(s.p(s.fG, t, c), g);
+        }
         a02n = d.a02; a12n = d.a12;
     }
+    return gmax;
 }
 
 // Diagonal entries (0, 0) and (1, 1) of the condensed H, the largest ones up to the input
@@ -427,9 +433,9 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
             for (int c = 0; c < 2; ++c) {
                 const bool hb = p.hb(t, c), hr = p.hr(c) && t + 1 < T;
                 s.st(s.p(s.fW, t, c), wc[c]);
-                s.st(s.p(s.fLU, t, c), hb ? kMu0 * rcp_nr(dmax(p.hi(t, c) - wc[c], kSlackMin)) : 0.0);
-                s.st(s.p(s.fLL, t, c), hb ? kMu0 * rcp_nr(dmax(wc[c] - p.lo(t, c), kSlackMin)) : 0.0);
-                const double l0 = hr ? kMu0 * rcp_nr(p.fb.rr[c]) : 0.0;
+                s.st(s.p(s.fLU, t, c), hb ? p.mu0 * rcp_nr(dmax(p.hi(t, c) - wc[c], kSlackMin)) : 0.0);
+                s.st(s.p(s.fLL, t, c), hb ? p.mu0 * rcp_nr(dmax(wc[c] - p.lo(t, c), kSlackMin)) : 0.0);
+                const double l0 = hr ? p.mu0 * rcp_nr(p.fb.rr[c]) : 0.0;
                 s.st(s.p(s.fNU, t, c), l0);
                 s.st(s.p(s.fNL, t, c), l0);
             }
