@@ -12,8 +12,7 @@
 // Per-lane arrays (the iterate, the stage dynamics, the Riccati gains) live in a global
 // workspace, one contiguous chunk per wavefront laid out [stage][field][lane]: every access of
 // a wavefront is one contiguous 512-byte row and each sweep over the stages streams through the
-// chunk in address order.  The solver itself is the one the
-// other kernels use: a fixed number of predictor-corrector interior-point iterations to find
+// chunk in address order.  The solver itself is the one the other kernels use: a fixed number of predictor-corrector interior-point iterations to find
 // the active set, primal-dual active-set rounds that certify the KKT conditions, and for
 // whatever does not settle a converged interior-point solve and the rounds again.
 #pragma once
@@ -50,9 +49,7 @@ struct Store {
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t lane_bytes;
     int T;
-    // rows of 512 bytes per wavefront chunk, made odd so that the chunks of consecutive wavefronts,
-    // which sweep their stages in near lockstep, start on different memory channels
-    __host__ __device__ static int64_t doubles_per_instance(int T) { return (int64_t)(kFields * T) | 1; }
+    __host__ __device__ static int64_t doubles_per_instance(int T) { return (int64_t)kFields * T; }
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     // ws: the workspace; wave: index of this wavefront's chunk (uniform); lane: 0..63
     __device__ __forceinline__ void bind(double *ws, int T_, int64_t wave, int lane)
@@ -265,7 +262,6 @@ __device__ __forceinline__ void riccati_vector_step(const Store &s, int t, const
 
 __device__ __forceinline__ void load_gains(const Store &s, int t, double (&Lx)[2][3], double (&Lv)[2][2])
 {
-    const int T = s.T;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -310,7 +306,6 @@ __device__ __forceinline__ void forward(const Store &s, F &&sink)
 // Adjoint state entering stage t's gradient: lambda_{t+1} = qe_t + A_{t+1}' lambda_{t+2}.
 __device__ __forceinline__ void adjoint_step(const Store &s, int t, double a02n, double a12n, double (&lam)[3])
 {
-    const int T = s.T;
     const double l2 = fma(a02n, lam[0], fma(a12n, lam[1], lam[2]));   // a*n = 0 at the last stage
     lam[0] = lam[0] + s.ld(s.f(s.fQe, t));
     lam[1] = lam[1] + s.ld(s.f(s.fQe + 1, t));
