@@ -93,3 +93,34 @@ def test_engine_fails_loudly_without_gpu():
         engine.solve_batch(variants.get("diff_drive"), np.zeros((1, 3)), np.zeros((1, 3, 6)))
     with pytest.raises(_lib.MpcxError):
         mpc_diff_drive.get_linear_model_matrix(0.3, 0.7)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """A C99 program that includes include/mpcx.h, links the library and calls the entry points
+    that need no GPU: what a cgo / JNI / C caller of the boundary would do."""
+    import os
+    import shutil
+    import subprocess
+    from model_predictive_control_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    _lib.load()
+    libdir = os.path.join(root, "model_predictive_control_amd", "lib")
+    src = tmp_path / "caller.c"
+    src.write_text(
+        "#include <stdio.h>\n#include <string.h>\n#include \"mpcx.h\"\n"
+        "int main(void) {\n"
+        "    mpcx_variant v;\n"
+        "    if (mpcx_abi_version() != MPCX_ABI_VERSION) return 1;\n"
+        "    if (mpcx_variant_by_name(\"dsr_ackermann\", &v) != 0) return 2;\n"
+        "    if (v.T != 5 || v.nu != 4) return 3;\n"
+        "    if (mpcx_workspace_bytes(&v, 65536) != 0) return 4;\n"
+        "    if (mpcx_variant_by_name(\"nope\", &v) == 0 || !strstr(mpcx_last_error(), \"unknown\")) return 5;\n"
+        "    puts(\"ok\");\n    return 0;\n}\n")
+    exe = tmp_path / "caller"
+    subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src),
+                    "-L", libdir, "-lmpcx", "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=60)
+    assert out.stdout.strip() == "ok"
