@@ -514,7 +514,6 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
 #endif
 constexpr int kStageIpmIters = MPCX_STAGE_K;   // interior-point iterations before the active-set rounds
 constexpr int kStageRounds0 = MPCX_STAGE_R0, kStageRounds1 = 5;
-constexpr int64_t kWaveBatchMax = 1024;   // below this many instances the wavefront-per-instance kernel is used where it applies
 
 template <int MODEL>
 __global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *ws)
@@ -1110,19 +1109,30 @@ static int64_t stage_chunk(int64_t B)
 // =0 every one the wavefront-per-instance kernel can take to that kernel
 static const int g_stagewise = [] { const char *e = getenv("MPCX_STAGEWISE"); return e ? atoi(e) : -1; }();
 
+// Largest batch the wavefront-per-instance kernel takes: what the chip holds at once (256 CUs,
+// per CU as many wavefronts as LDS and registers allow).  One such round takes less than the
+// latency of a single stage-wise wavefront (T = 30: 0.93 ms against 1.58 ms; T = 12: 0.25-0.38 ms
+// against 0.64 ms); a second round does not.
+static int64_t wave_batch_max(int T)
+{
+    const int64_t by_lds = (160 * 1024) / ((int64_t)wave_lds_doubles(T) * (int64_t)sizeof(double));
+    const int64_t by_regs = 12;   // 3 wavefronts per SIMD at the kernel's register count
+    return 256 * (by_lds < by_regs ? by_lds : by_regs);
+}
+
 enum SolvePath { kPathPair5, kPathReg5, kPathPair10, kPathWave, kPathStage };
 
 // T = 5 with every bound present: lane-pair kernel, chained or not.  T = 10 (mpc.py) with both
-// boxes present, unchained: its T = 10 instantiation.  Other horizons: small batches of
-// unchained solves up to T = 32 go one wavefront per instance (lower latency: 64 lanes share
-// one instance), everything else one lane per instance with stage-wise linear algebra (far
+// boxes present, unchained: its T = 10 instantiation.  Other horizons: batches of unchained
+// solves up to T = 32 that the chip holds at once go one wavefront per instance (lower latency:
+// 64 lanes share one instance), everything else one lane per instance with stage-wise linear algebra (far
 // higher throughput once the chip is filled).
 static SolvePath choose_path(const mpcx_variant *v, int64_t B, bool chained)
 {
     if (uses_registers(v)) return g_force_single_lane ? kPathReg5 : kPathPair5;
     if (v->T == 10 && boxes_present(v) && !chained && !g_force_single_lane) return kPathPair10;
     const bool wave_fits = v->T <= 32 && !chained;
-    if (wave_fits && (g_stagewise >= 0 ? g_stagewise == 0 : B < kWaveBatchMax)) return kPathWave;
+    if (wave_fits && (g_stagewise >= 0 ? g_stagewise == 0 : B <= wave_batch_max(v->T))) return kPathWave;
     return kPathStage;
 }
 

@@ -48,7 +48,7 @@ def test_closed_loop_matches_oracle_loop(name):
     assert np.median(np.hypot(*(log[-1][:, :2] - log[0][:, :2]).T)) > 0.05
 
 
-@pytest.mark.parametrize("B", [96, 1100])
+@pytest.mark.parametrize("B", [96, 3200])
 def test_closed_loop_at_a_long_horizon(B):
     """T = 12: the wavefront-per-instance kernel (small fleet) and the stage-wise kernel (large
     fleet, with its workspace) inside the tick."""

@@ -55,7 +55,7 @@ def test_random_controller(eng, seed):
     rng = np.random.default_rng(1000 + seed)
     base = BASES[seed % len(BASES)]
     ov_kw = _random_overrides(rng, base)
-    B = int(rng.choice([1, 7, 64, 65, 130, 1024, 1200]))
+    B = int(rng.choice([1, 7, 64, 65, 130, 1200, 3500]))
     v, ov, x0, xref = make_problem(base, B, seed=50 + seed, **ov_kw)
     ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
     out = eng.solve_batch(v, x0, xref)

@@ -216,10 +216,10 @@ def test_mpc_py_horizon_10_lane_pair_kernel(eng):
     compare(outl, refl)
 
 
-@pytest.mark.parametrize("T,B", [(16, 300), (16, 1024 + 37), (40, 200)])
+@pytest.mark.parametrize("T,B", [(16, 300), (16, 3072 + 37), (40, 200)])
 def test_long_horizon_kernels_edge_cases(eng, T, B):
-    """Horizons other than 5 and 10: small batches up to T = 32 run one wavefront per instance,
-    larger batches and longer horizons one lane per instance with stage-wise linear algebra.
+    """Horizons other than 5 and 10: batches the chip holds at once (3,072 instances at T = 16) run
+    one wavefront per instance up to T = 32, larger batches and longer horizons one lane per instance with stage-wise linear algebra.
     Warm/cold mix, non-finite and infeasible instances, tiny batches, absent bounds, and the
     one-QP entry point, for each."""
     v, ov, x0, xref = make_problem("dsr_ackermann", B, seed=21, T=T)
