@@ -262,7 +262,7 @@ def test_long_horizons(eng):
     global-workspace kernel (longer, or chained)."""
     for name, T, B in (("mpc_py", 10, 1024), ("dsr_ackermann", 30, 512), ("diff_drive", 12, 512),
                        ("dsr_crab", 32, 256), ("dsr_ackermann", 40, 128), ("sim_ackermann", 8, 256),
-                       ("diff_drive", 1, 256), ("dsr_ackermann", 2, 256)):
+                       ("diff_drive", 1, 256), ("dsr_ackermann", 2, 256), ("diff_drive", 64, 96)):
         v, ov, x0, xref = make_problem(name, B, T=T)
         ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
         out = eng.solve_batch(v, x0, xref)
