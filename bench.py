@@ -45,6 +45,16 @@ def measured_traffic():
         return None
 
 
+def measured_valu_busy():
+    """Fraction of the solve kernel's wave cycles that issue a VALU instruction, from the SQ
+    counter passes recorded in profiles/ (scripts/pmc_pair.sh); None if not recorded."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pair5_sq_counters.json")) as f:
+            return float(json.load(f)["valu_busy_frac"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def algorithmic_bytes(nu: int, T: int) -> int:
     """Compulsory traffic of one solve at the float64 API: read xref 24(T+1), x0 24, uprev
     8 NU T, has_prev 1; write u 8 NU T, x 24(T+1), obj 8, status 4, iters 4."""
@@ -226,6 +236,7 @@ def main():
                          "kernel_ms_note": "HIP events on the launch stream, back-to-back launches: includes the ~4 us "
                                            "dispatch gap between consecutive kernels that a kernel trace leaves out",
                          "algorithmic_bytes_per_solve": algorithmic_bytes(v.nu, v.T),
+                         "valu_busy_frac": measured_valu_busy() if B == BATCH else None,
                          "note": "the solve is FP64-VALU issue bound (5 interior-point iterations + ~4 active-set "
                                  "rounds, one 10x10 Cholesky each, per instance); HBM fraction reported as the task asks"},
         }
