@@ -19,6 +19,7 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
     __shared__ int Fs[kWave];
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     constexpr int T = MPCX_PAIR_NS::TT, W = T + 1;
+    constexpr int kFixedIters = T > 5 ? kPairIpmIters10 : kPairIpmIters;
     constexpr int SX = MPCX_PAIR_NS::padded(3 * W), SU = MPCX_PAIR_NS::padded(NU * T), S0 = MPCX_PAIR_NS::padded(3);   // record strides in LDS
     constexpr int kInU = MPCX_PAIR_NS::kPairs * S0, kInXbar = kInU + MPCX_PAIR_NS::kPairs * SU;
     static_assert(kInXbar + MPCX_PAIR_NS::kPairs * SX <= MPCX_PAIR_NS::kLdsPerLane * kWave, "input staging must fit in the H area");
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
 #pragma unroll 1
         for (int attempt = 0; attempt < 2; ++attempt) {
             int st = MPCX_ST_OK, it = 0;
-            MPCX_PAIR_NS::ipm(s, attempt == 0 ? (a.max_iter < kPairIpmIters ? a.max_iter : kPairIpmIters) : a.max_iter, attempt == 0,
+            MPCX_PAIR_NS::ipm(s, attempt == 0 ? (a.max_iter < kFixedIters ? a.max_iter : kFixedIters) : a.max_iter, attempt == 0,
                       !need, st, it);
             if (pass == 0) MPCX_STAMP(2 + 2 * attempt);
             if (need) { iters += it; status = st; }
