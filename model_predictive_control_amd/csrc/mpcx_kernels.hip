@@ -251,7 +251,10 @@ namespace mpcx {
 // ------------------------------------------------------------------------------------
 // solve: one wavefront per instance (horizons beyond the lane-pair kernels, n = 2T <= 64)
 // ------------------------------------------------------------------------------------
-constexpr int kWaveIpmIters = 6;   // interior-point iterations before the active-set rounds
+#ifndef MPCX_WAVE_K
+#define MPCX_WAVE_K 5
+#endif
+constexpr int kWaveIpmIters = MPCX_WAVE_K;   // interior-point iterations before the active-set rounds
 constexpr int kWaveRounds0 = 8, kWaveRounds1 = 5;
 
 __host__ __device__ inline int wave_lds_doubles(int T)
