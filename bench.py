@@ -131,7 +131,8 @@ def other_configs(steps: int = 3):
                                ("dsr_ackermann", 65536, 30, "k_solve_stage<dual-steer>")):
         v = variants.get(name, T=T) if T else variants.get(name)
         inst = workload.make_instances(courses, B, seed=2003)
-        d_xref = torch.from_numpy(workload.reference_window(courses, inst, v.T)).cuda()
+        window = workload.reference_window_next_points if name == "mpc_py" else workload.reference_window
+        d_xref = torch.from_numpy(window(courses, inst, v.T)).cuda()
         d_x0 = torch.from_numpy(inst["state"][:, :3].copy()).cuda()
         out = engine.solve_batch(v, d_x0, d_xref)
         up = out["u"].clone()

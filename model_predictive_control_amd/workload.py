@@ -60,3 +60,17 @@ def reference_window(courses, inst, T: int, n_ahead: int = 2) -> np.ndarray:
         xref[b, :, 0] = (cx[ind], cy[ind], cyaw[ind])
         xref[b, :, 1:] = np.array([cx[nxt], cy[nxt], cyaw[nxt]])[:, None]
     return xref
+
+
+def reference_window_next_points(courses, inst, T: int, stride: int = 3) -> np.ndarray:
+    """Host-side xref [B,3,T+1] the way mpc.py builds it: the next T+1 points of the (pruned)
+    recorded trajectory ahead of the robot (mpc.py:292-296), here every `stride`-th point of
+    the synthetic course from the instance's index on, the last point repeated at the end."""
+    B = inst["state"].shape[0]
+    xref = np.empty((B, 3, T + 1))
+    steps = stride * np.arange(T + 1)
+    for b in range(B):
+        cx, cy, cyaw = courses[inst["course_id"][b]]
+        idx = np.minimum(int(inst["pind"][b]) + steps, len(cx) - 1)
+        xref[b] = np.stack([cx[idx], cy[idx], cyaw[idx]])
+    return xref

@@ -21,13 +21,7 @@ def make_problem(name, B, seed=7, n_courses=16, **overrides):
     courses = workload.make_courses(n_courses)
     inst = workload.make_instances(courses, B, seed=seed)
     if name == "mpc_py":
-        # mpc.py takes the next HL+1 course points as reference (mpc.py:292-296)
-        xref = np.empty((B, 3, v.T + 1))
-        for b in range(B):
-            cx, cy, cyaw = courses[inst["course_id"][b]]
-            p = int(inst["pind"][b])
-            idx = np.minimum(p + 3 * np.arange(v.T + 1), len(cx) - 1)
-            xref[b] = np.stack([cx[idx], cy[idx], cyaw[idx]])
+        xref = workload.reference_window_next_points(courses, inst, v.T)   # mpc.py:292-296
     else:
         xref = workload.reference_window(courses, inst, v.T)
     return v, ov, inst["state"][:, :3].copy(), xref
