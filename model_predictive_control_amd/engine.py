@@ -339,3 +339,73 @@ class ClosedLoop:
     @property
     def last_u(self):
         return self.uprev
+
+
+class HostPipeline:
+    """Solves for callers whose data lives in host memory: batches go host -> device -> solve ->
+    host through `depth` slots, each with pinned host buffers, device buffers and a HIP stream
+    of its own, so the upload of one batch, the solve of another and the download of a third
+    overlap (the link carries about 650 bytes per instance each way combined; the solve itself
+    is an order of magnitude shorter than either copy).
+
+        pipe = HostPipeline(v, B)
+        slot = pipe.acquire()                 # waits until the slot's previous batch is done
+        slot.x0[:] = ...; slot.xref[:] = ...  # numpy views of the pinned input buffers
+        slot.uprev[:] = ...; slot.has_prev[:] = ...
+        pipe.submit(slot, warm=True)          # enqueues copy-in, solve, copy-out; returns at once
+        ...
+        res = pipe.result(slot)               # waits for that batch; numpy views of pinned outputs
+
+    Results stay valid until the slot is acquired again."""
+
+    class Slot:
+        pass
+
+    def __init__(self, v: CVariant, B: int, depth: int = 3):
+        dev = _device()
+        self.v, self.B, self.depth = v, int(B), int(depth)
+        T, NU = v.T, v.nu
+        shapes = dict(x0=((B, 3), torch.float64), xref=((B, 3, T + 1), torch.float64),
+                      uprev=((B, NU, T), torch.float64), has_prev=((B,), torch.uint8))
+        self._slots = []
+        for _ in range(self.depth):
+            s = HostPipeline.Slot()
+            s.stream = torch.cuda.Stream(device=dev)
+            s.done = torch.cuda.Event()
+            s.busy = False
+            s.h_in = {k: torch.empty(shp, dtype=dt).pin_memory() for k, (shp, dt) in shapes.items()}
+            s.d_in = {k: torch.empty(shp, dtype=dt, device=dev) for k, (shp, dt) in shapes.items()}
+            s.d_out = _outputs(B, NU, T, dev)
+            s.h_out = {k: torch.empty_like(t, device="cpu").pin_memory() for k, t in s.d_out.items()}
+            for k, t in s.h_in.items():
+                setattr(s, k, t.numpy())
+            s.out = {k: t.numpy() for k, t in s.h_out.items()}
+            self._slots.append(s)
+        self._next = 0
+
+    def acquire(self):
+        s = self._slots[self._next]
+        self._next = (self._next + 1) % self.depth
+        if s.busy:
+            s.done.synchronize()
+            s.busy = False
+        return s
+
+    def submit(self, s, warm: bool = True):
+        with torch.cuda.stream(s.stream):
+            names = ("x0", "xref", "uprev", "has_prev") if warm else ("x0", "xref")
+            for k in names:
+                s.d_in[k].copy_(s.h_in[k], non_blocking=True)
+            solve_batch(self.v, s.d_in["x0"], s.d_in["xref"], s.d_in["uprev"] if warm else None,
+                        s.d_in["has_prev"] if warm else None, out=s.d_out)
+            for k in s.d_out:
+                s.h_out[k].copy_(s.d_out[k], non_blocking=True)
+            s.done.record(s.stream)
+        s.busy = True
+        return s
+
+    def result(self, s):
+        if s.busy:
+            s.done.synchronize()
+            s.busy = False
+        return s.out

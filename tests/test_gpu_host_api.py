@@ -158,3 +158,25 @@ def test_mpc_py_controller_tick():
         assert out.shape == (3, 1)
         np.testing.assert_allclose(out.reshape(3), [vx, vy, w], atol=5e-5)
     assert len(ctl.predict_state_) == 20
+
+
+def test_host_pipeline_matches_resident_solve():
+    """Batches handed over in host memory through the three-slot pipeline (pinned buffers, a
+    stream per slot) give what the resident solve gives, batch by batch, cold and warm."""
+    from model_predictive_control_amd import engine
+    from tests.helpers import make_problem
+    B = 700
+    pipe = engine.HostPipeline(make_problem("dsr_ackermann", 1)[0], B, depth=3)
+    problems, slots = [], []
+    for k in range(5):                      # more batches than slots: slots are reused
+        v, ov, x0, xref = make_problem("dsr_ackermann", B, seed=100 + k)
+        warm = k % 2 == 1
+        up = np.zeros((B, 4, 5)); up[:, 0] = up[:, 2] = 0.1 * k
+        hp = (np.arange(B) % 2).astype(np.uint8)
+        want = engine.solve_batch(v, x0, xref, up if warm else None, hp if warm else None)
+        s = pipe.acquire()
+        s.x0[:] = x0; s.xref[:] = xref; s.uprev[:] = up; s.has_prev[:] = hp
+        pipe.submit(s, warm=warm)
+        got = {k2: a.copy() for k2, a in pipe.result(s).items()}
+        for key in ("u", "x", "obj", "status"):
+            np.testing.assert_array_equal(got[key], want[key].cpu().numpy())
