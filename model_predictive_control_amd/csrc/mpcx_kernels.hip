@@ -1103,6 +1103,10 @@ static const bool g_force_single_lane = [] { const char *e = getenv("MPCX_SINGLE
 static std::mutex g_ws_mutex;
 static double *g_ws[64] = {nullptr};
 static size_t g_ws_bytes[64] = {0};
+// the workspace has one user at a time: a call waits (on the device, not the host) for the
+// previous call's last launch, whatever stream that ran on
+static hipEvent_t g_ws_event[64] = {nullptr};
+static bool g_ws_event_set[64] = {false};
 
 static int64_t stage_doubles_per_instance(int T) { return stagewise::Store::doubles_per_instance(T); }
 // instances per launch of the stage-wise kernel (bounds the workspace)
@@ -1219,6 +1223,14 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
         if (e != hipSuccess) return fail(MPCX_E_NOMEM, "workspace of %zu bytes: %s", need, hipGetErrorString(e));
         g_ws_bytes[dev] = need;
     }
+    if (!g_ws_event[dev]) {
+        e = hipEventCreateWithFlags(&g_ws_event[dev], hipEventDisableTiming);
+        if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+    }
+    if (g_ws_event_set[dev]) {
+        e = hipStreamWaitEvent(st, g_ws_event[dev], 0);
+        if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+    }
     for (int64_t off = 0; off < a.B; off += chunk) {
         SolveArgs c = a;
         c.B = a.B - off < chunk ? a.B - off : chunk;
@@ -1238,6 +1250,9 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
         e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_solve_stage launch");
     }
+    e = hipEventRecord(g_ws_event[dev], st);
+    if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
+    g_ws_event_set[dev] = true;
     return 0;
 }
 

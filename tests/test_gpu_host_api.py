@@ -180,3 +180,26 @@ def test_host_pipeline_matches_resident_solve():
         got = {k2: a.copy() for k2, a in pipe.result(s).items()}
         for key in ("u", "x", "obj", "status"):
             np.testing.assert_array_equal(got[key], want[key].cpu().numpy())
+
+
+def test_long_horizon_solves_on_different_streams_do_not_share_the_workspace_at_once():
+    """The stage-wise kernel's workspace has one user at a time: calls enqueued on three streams
+    back to back must each give the answer they give alone."""
+    import torch
+    from model_predictive_control_amd import engine
+    from tests.helpers import make_problem
+    B, T = 4000, 14
+    probs = [make_problem("dsr_ackermann", B, seed=200 + k, T=T) for k in range(3)]
+    alone = [engine.solve_batch(p[0], p[2], p[3])["u"].cpu().numpy() for p in probs]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    dev_in = [(torch.from_numpy(p[2]).cuda(), torch.from_numpy(p[3]).cuda()) for p in probs]
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):
+        outs = []
+        for s, p, (x0, xref) in zip(streams, probs, dev_in):
+            with torch.cuda.stream(s):
+                outs.append(engine.solve_batch(p[0], x0, xref))
+        torch.cuda.synchronize()
+        for o, want in zip(outs, alone):
+            np.testing.assert_array_equal(o["u"].cpu().numpy(), want)
