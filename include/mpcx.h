@@ -88,11 +88,12 @@ int mpcx_variant_by_name(const char *name, mpcx_variant *out);
 
 /* Bytes of device workspace mpcx_solve_batch / mpcx_linear_mpc_batch need for B
  * instances of this variant: 0 for the kernels that live in registers and LDS (T = 5,
- * T = 10, and batches up to T = 32 that the chip holds at once), otherwise the per-lane arrays of the stage-wise
- * kernel for one launch (472 T bytes per instance, at most 262,144 instances per launch).  The library keeps one grow-only buffer per device
- * for it; calls that need it are serialised per device (each waits on the device for the
- * previous one, whatever its stream), the first one allocates, and none of them may be part of
- * a stream capture. */
+ * T = 10, and batches up to T = 32 that the chip holds at once), otherwise the per-lane
+ * arrays of the stage-wise kernel for one launch (472 T bytes per instance, at most
+ * 262,144 instances per launch).  The library keeps one grow-only buffer per device for
+ * it; calls that need it are serialised per device (each waits on the device for the
+ * previous one, whatever its stream), the first one allocates, and none of them may be
+ * part of a stream capture. */
 int64_t mpcx_workspace_bytes(const mpcx_variant *v, int64_t B);
 
 /* iterative_linear_mpc_control (mpc_diff_drive.py:142-167, mpc_dsr.py:169-199),
