@@ -13,6 +13,16 @@ import numpy as np
 from . import _scalar, variants
 
 
+class State:
+    """Pose, body twist and wheel commands of the dual-steer platform (mpc.py:13-27)."""
+
+    def __init__(self, x, y, yaw, vx, vy, w, front_steer, front_speed, rear_steer, rear_speed) -> None:
+        self.x_, self.y_, self.yaw_ = x, y, yaw
+        self.vx_, self.vy_, self.w_ = vx, vy, w
+        self.front_steer_, self.front_speed_ = front_steer, front_speed
+        self.rear_steer_, self.rear_speed_ = rear_steer, rear_speed
+
+
 class ModelPredictiveControl:
 
     def __init__(self) -> None:
@@ -156,6 +166,30 @@ class ModelPredictiveControl:
             x_ref[0, i] = self.pts_x_[i]
             x_ref[1, i] = self.pts_y_[i]
             x_ref[2, i] = self.pts_yaw_[i]
+        return x_ref
+
+    def getReferenceTrajectoryWithLookAheadDistance(self, x_current):
+        """Reference window from the raw node list (mpc.py:300-345): drops every node up to the
+        LAST one closer than trim_dist_ (in place), walks on from the first remaining node while
+        the travelled distance stays within LOOKAHEAD_DIST_, and fills the HL+1 columns from the
+        back with the nodes walked over, the first of them repeated in front."""
+        if not self.isReferenceRetrived_:
+            return None
+        ref = self.reference_
+        px, py = float(np.ravel(x_current[0])[0]), float(np.ravel(x_current[1])[0])
+        near = [i for i, n in enumerate(ref) if math.sqrt((px - n[0]) ** 2 + (py - n[1]) ** 2) < self.trim_dist_]
+        if near:
+            del ref[:near[-1] + 1]
+        m, travel = min(1, len(ref)), 0
+        while m < len(ref):
+            travel = travel + math.sqrt((ref[m][0] - ref[m - 1][0]) ** 2 + (ref[m][1] - ref[m - 1][1]) ** 2)
+            if travel > self.LOOKAHEAD_DIST_:
+                break
+            m += 1
+        x_ref = np.zeros((self.NX_, self.HL_ + 1))
+        for j in range(self.HL_ + 1):
+            node = ref[max(0, m - 1 - (self.HL_ - j))]
+            x_ref[:, j] = node[:3]
         return x_ref
 
     def updateCurrentState(self, x, y, yaw):

@@ -217,6 +217,21 @@ def main():
         poses.append(pose.reshape(3))
     g.update(mpcpy_prune_pose=np.array(poses), mpcpy_prune_xref=np.array(prn), mpcpy_prune_len=np.array(lens))
 
+    # ---- mpc.py reference window by look-ahead distance (mpc.py:300-345), stateful like the above
+    ctl3 = mpc.ModelPredictiveControl()
+    ctl3.isReferenceRetrived_ = True
+    ctl3.reference_ = [[float(ex[i]), float(ey[i]), float(sm[i])] for i in range(0, 240, 2)]
+    la_pose, la_xref, la_len, la_dist = [], [], [], []
+    for j, dist in ((0, 1.0), (4, 1.0), (4, 0.3), (20, 2.5), (21, 0.05), (50, 6.0), (110, 1.0)):
+        ctl3.LOOKAHEAD_DIST_ = dist
+        pose = np.array([[ex[j] + 0.03], [ey[j] + 0.04], [sm[j]]])
+        la_xref.append(ctl3.getReferenceTrajectoryWithLookAheadDistance(pose))
+        la_len.append(len(ctl3.reference_))
+        la_pose.append(pose.reshape(3))
+        la_dist.append(dist)
+    g.update(mpcpy_la_pose=np.array(la_pose), mpcpy_la_xref=np.array(la_xref), mpcpy_la_len=np.array(la_len),
+             mpcpy_la_dist=np.array(la_dist))
+
     # ---- node-list preprocessing: ICR-arc / crab interpolation, de-duplication, mode split ------
     # synthetic node lists in the CSV schema x | y | yaw | vx | vy | w | ... | time | mode
     n_nodes = 14

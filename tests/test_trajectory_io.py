@@ -69,3 +69,22 @@ def test_reference_named_wrappers(golden):
     np.testing.assert_allclose(np.array(a), golden["interp_crab_5"], atol=1e-13)
     assert gen.splitTrajectoryWithMotionModes(["a", "a", "b", "b"]) == [[0, 1]]
     assert mpc_dsr.removeRepeatedPoints([0, 0, 1], [0, 0, 1], [1, 2, 3]) == ([0, 1], [0, 1], [1, 3])
+
+
+def test_mpc_py_reference_window_by_look_ahead_distance():
+    """ModelPredictiveControl.getReferenceTrajectoryWithLookAheadDistance against the windows and
+    the in-place pruning the reference's method produced on the same node list and poses."""
+    import os
+    from model_predictive_control_amd import mpc
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+    ctl = mpc.ModelPredictiveControl()
+    ctl.isReferenceRetrived_ = True
+    ex, ey, sm = g["eight_x"], g["eight_y"], g["eight_yaw_smooth"]
+    ctl.reference_ = [[float(ex[i]), float(ey[i]), float(sm[i])] for i in range(0, 240, 2)]
+    for pose, want, ln, dist in zip(g["mpcpy_la_pose"], g["mpcpy_la_xref"], g["mpcpy_la_len"], g["mpcpy_la_dist"]):
+        ctl.LOOKAHEAD_DIST_ = float(dist)
+        got = ctl.getReferenceTrajectoryWithLookAheadDistance(pose.reshape(3, 1))
+        assert np.array_equal(got, want)
+        assert len(ctl.reference_) == ln
+    st = mpc.State(1, 2, 3, 4, 5, 6, 7, 8, 9, 10)
+    assert (st.x_, st.w_, st.rear_speed_) == (1, 6, 10)
