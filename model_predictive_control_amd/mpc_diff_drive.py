@@ -186,5 +186,11 @@ def main(max_ticks=None):
     return do_simulation(cx, cy, cyaw, dl, initial_state, max_ticks=max_ticks)
 
 
+
+def main2():
+    """The figure-eight course itself (the reference plots it; mpc_diff_drive.py:472-476)."""
+    return makeEightShapeTrajectory(400, 10)
+
+
 if __name__ == "__main__":
     main()

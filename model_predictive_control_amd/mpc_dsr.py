@@ -222,3 +222,37 @@ def interpolateReference(node_lists, interpolate_num=5, mode='ackermann'):
 
 def removeRepeatedPoints(cx, cy, cyaw, epsilon=0.00001):
     return trajectory_io.remove_repeated_points(cx, cy, cyaw, epsilon)
+
+
+# --- scenario drivers (mpc_dsr.py:623-695; no plotting, the recorded file is an argument) --------
+
+def _run_course(cx, cy, cyaw, max_ticks=None):
+    cx, cy, cyaw = list(cx), list(cy), list(cyaw)
+    initial_state = State(x=cx[0], y=cy[0], yaw=cyaw[0])
+    cx.pop(0); cy.pop(0); cyaw.pop(0)
+    return do_simulation(cx, cy, cyaw, 0.5, initial_state, max_ticks=max_ticks)
+
+
+def _run_recorded(file_name, interpolate_num, mode, max_ticks):
+    cx, cy, cyaw = interpolateReference(retriveReferenceFromCSV(file_name), interpolate_num, mode)
+    return _run_course(*removeRepeatedPoints(cx, cy, cyaw), max_ticks=max_ticks)
+
+
+def main(max_ticks=None):
+    """Figure-eight course."""
+    return _run_course(*makeEightShapeTrajectory(400, 10), max_ticks=max_ticks)
+
+
+def main2(file_name='reference.csv', max_ticks=None):
+    """Recorded trajectory, ICR-arc interpolation."""
+    return _run_recorded(file_name, 3, 'ackermann', max_ticks)
+
+
+def main3(file_name='reference_crab.csv', max_ticks=None):
+    """Recorded crab trajectory, straight-line interpolation."""
+    return _run_recorded(file_name, 3, 'crab', max_ticks)
+
+
+def main4(file_name='reference_diff.csv', max_ticks=None):
+    """Recorded trajectory for the fixed-steer mode (interpolated as the reference does: 'crab')."""
+    return _run_recorded(file_name, 2, 'crab', max_ticks)

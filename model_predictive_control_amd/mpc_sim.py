@@ -230,3 +230,44 @@ class TrajectoryGenerator:
             dy = math.cos(1 * math.pi / 60 * i) * 1 * math.pi / 60
             yaw.append(math.atan2(dy, dx))
         return x, y, yaw
+
+
+# --- scenario drivers (mpc_sim.py:706-784; no plotting, the recorded file is an argument) --------
+
+def _run_course(cx, cy, cyaw, mode, max_ticks):
+    cx, cy, cyaw = list(cx), list(cy), list(cyaw)
+    initial_state = State(x=cx[0], y=cy[0], yaw=cyaw[0])
+    cx.pop(0); cy.pop(0); cyaw.pop(0)
+    return MPC().doSimulation(cx, cy, cyaw, initial_state, mode, max_ticks=max_ticks)
+
+
+def _run_recorded(file_name, interpolate_num, mode, max_ticks):
+    tg = TrajectoryGenerator()
+    cx, cy, cyaw = tg.interpolateReference(tg.retriveTrajectoryFromCSV(file_name), interpolate_num, mode)
+    return _run_course(*tg.removeRepeatedPoints(cx, cy, cyaw), mode=mode, max_ticks=max_ticks)
+
+
+def main1(max_ticks=None):
+    """Figure-eight course, ackermann mode."""
+    return _run_course(*TrajectoryGenerator().makeEightShapeTrajectory(), mode='ackermann', max_ticks=max_ticks)
+
+
+def main2(file_name='reference.csv', max_ticks=None):
+    return _run_recorded(file_name, 3, 'ackermann', max_ticks)
+
+
+def main3(file_name='reference_crab.csv', max_ticks=None):
+    return _run_recorded(file_name, 3, 'crab', max_ticks)
+
+
+def main4(file_name='reference_diff.csv', max_ticks=None):
+    return _run_recorded(file_name, 2, 'diff', max_ticks)
+
+
+def main5(file_name='output.csv'):
+    """Recorded trajectory with a motion mode per node: one simulation per mode segment."""
+    tg = TrajectoryGenerator()
+    cx, cy, cyaw, cmode = tg.interpolateReference2(tg.retriveTrajectoryFromCSV(file_name), 3)
+    idx_group = tg.splitTrajectoryWithMotionModes(cmode)
+    initial_state = State(x=cx[0], y=cy[0], yaw=cyaw[0])
+    return MPC().doSimulationWithAllMotionModes(idx_group, cx, cy, cyaw, cmode, initial_state)
