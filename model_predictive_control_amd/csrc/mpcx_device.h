@@ -44,6 +44,10 @@ constexpr double kLooseMu = 1e-7;
 constexpr double kEtaCap = 0.999;
 constexpr double kMinWidth = 2e-9;    // a first-stage window narrower than this is widened to it
 constexpr double kBig = 1e300;
+#ifndef MPCX_RHO_CAP
+#define MPCX_RHO_CAP 1e10
+#endif
+constexpr double kRhoCap = MPCX_RHO_CAP;      // largest penalty parameter of the active-set rounds (long-horizon kernels)
 
 __device__ __forceinline__ double rcp_raw(double x) { return __builtin_amdgcn_rcp(x); }
 __device__ __forceinline__ double rcp_nr(double x)

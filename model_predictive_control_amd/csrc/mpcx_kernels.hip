@@ -252,7 +252,7 @@ namespace mpcx {
 // solve: one wavefront per instance (horizons beyond the lane-pair kernels, n = 2T <= 64)
 // ------------------------------------------------------------------------------------
 #ifndef MPCX_WAVE_K
-#define MPCX_WAVE_K 5
+#define MPCX_WAVE_K 6
 #endif
 constexpr int kWaveIpmIters = MPCX_WAVE_K;   // interior-point iterations before the active-set rounds
 constexpr int kWaveRounds0 = 8, kWaveRounds1 = 5;

@@ -687,7 +687,10 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
 __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_rounds, double hmax, bool run)
 {
     const int T = s.T;
-    const double rho = 1e5 * hmax;
+    // penalty of the augmented Lagrangian: 1e5 times the curvature scale, capped where weights that
+    // grow like 2^t would push it to 1e14 and the Newton step of the rounds into rounding noise
+    // (T = 30 fixed-steer variant: agreement with the oracle 5e-5 -> 2e-7 in the controls)
+    const double rho = dmin(1e5 * hmax, kRhoCap);
     const bool ran = run;
     // initial set: multiplier above slack; the same sweep rolls the dynamics for the first round
     if (__any(run)) {

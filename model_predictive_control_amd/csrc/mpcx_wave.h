@@ -346,7 +346,7 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
 {
     const int i = c.lane;
     const double wbak = c.w;
-    const double rho = 1e5 * hmax;
+    const double rho = dmin(1e5 * hmax, kRhoCap);
     bool au, al, bu, bl;
     {
         const double dv = from_next(c.w, i) - c.w;

@@ -289,3 +289,27 @@ def test_headline_batch_full_size(eng):
     # idempotence: the same batch again gives bit-identical output
     out2 = eng.solve_batch(v, x0, xref)
     assert np.array_equal(out2["u"].cpu().numpy(), u)
+
+
+@pytest.mark.parametrize("B", [512, 2048])
+def test_ill_conditioned_long_horizon(eng, B):
+    """The T = 30 fixed-steer variant (stage weights Q 2^t, cond(H) about 5e10), cold and warm,
+    through the wavefront-per-instance kernel (512) and the stage-wise kernel (2,048): the
+    optimum is flat, so single instances sit up to a few 1e-4 from the oracle's controls at the
+    same objective; the bar of 1e-3 holds for every instance both certify, the median is below
+    1e-6, and the GPU fails on no more than one instance in a thousand."""
+    v, ov, x0, xref = make_problem("dsr_diff", B, T=30)
+    ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
+    out = eng.solve_batch(v, x0, xref)
+    hp = (np.arange(B) % 3 != 0).astype(np.uint8)
+    ref2 = orc.iterative_batch(ov, x0, xref, ref["u"], hp, nthreads=8)
+    out2 = eng.solve_batch(v, x0, xref, ref["u"], hp)
+    for o, r in ((out, ref), (out2, ref2)):
+        st = o["status"].cpu().numpy()
+        assert (st <= 1).mean() >= 0.999
+        both = (st == 0) & (r["status"] == 0)
+        assert both.mean() > 0.98
+        du = np.abs(o["u"].cpu().numpy() - r["u"])[both].reshape(int(both.sum()), -1).max(axis=1)
+        assert du.max() <= U_BAR and np.median(du) <= 1e-6
+        rel = np.abs(o["obj"].cpu().numpy() - r["obj"])[both] / np.maximum(1.0, np.abs(r["obj"][both]))
+        assert rel.max() <= OBJ_BAR and np.median(rel) <= 1e-9
