@@ -93,7 +93,8 @@ int mpcx_variant_by_name(const char *name, mpcx_variant *out);
  * 262,144 instances per launch).  The library keeps one grow-only buffer per device for
  * it; calls that need it are serialised per device (each waits on the device for the
  * previous one, whatever its stream), the first one allocates, and none of them may be
- * part of a stream capture. */
+ * part of a stream capture.  The answer is for mpcx_solve_batch; for mpcx_linear_mpc_batch,
+ * which never chains, it is an upper bound when v->chain > 1. */
 int64_t mpcx_workspace_bytes(const mpcx_variant *v, int64_t B);
 
 /* iterative_linear_mpc_control (mpc_diff_drive.py:142-167, mpc_dsr.py:169-199),
@@ -130,7 +131,9 @@ int mpcx_linearize_batch(const mpcx_variant *v, int64_t B, const double *theta, 
  * mpc_diff_drive.py:271-296, mpc_sim.py:520-539).
  *   state [B][4] = x, y, yaw, vx;  course_id [B] (NULL = course 0);  pind [B];
  *   course tables cx, cy, cyaw [K][Lmax] with clen [K] valid points each;
- *   ind_out [B] (-1 = empty search window, where the reference raises);
+ *   ind_out [B] (-1 = empty search window, where the reference raises; also for a course_id
+ *   outside 0..n_courses-1 and for a course whose clen is not 1..Lmax); ind_out may be the
+ *   same buffer as pind (each instance reads its pind before its ind is written);
  *   mind_out [B] or NULL (signed as in mpc_diff_drive.py:116-121 when sign != 0);
  *   xref_out [B][3][T+1] or NULL. */
 int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int32_t n_search,
@@ -147,7 +150,8 @@ int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int
  *   u [B][NU][T], status [B]: outputs of mpcx_solve_batch;  target_ind [B]: ind_out of
  *   mpcx_nearest_ref_batch for this tick;  state [B][4] = x, y, yaw, vx (updated in place);
  *   twist [B][2] = vy, w of the applied command (or NULL);  done [B]: 0 running, 1 goal
- *   reached, 2 reference window lost (frozen from then on);  ticks [B]: ticks executed;
+ *   reached, 2 reference window lost, course_id outside the table or course length not
+ *   1..Lmax (frozen from then on);  ticks [B]: ticks executed;
  *   log_out [B][4] or NULL: the state after this tick. */
 int mpcx_advance_batch(const mpcx_variant *v, int64_t B, double goal_dis, double stop_speed, const double *u,
                        const int32_t *status, const int32_t *target_ind, const int32_t *course_id,

@@ -114,6 +114,7 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
         else { u[0] = w0; u[1] = w1; u[2] = w0; u[3] = sg * w1; }
     };
 
+    bool inaccurate = false;   // an inaccurate link makes the whole chain's answer inaccurate
     for (int pass = 0; pass < (STORED ? chain : 1); ++pass) {
         if (STORED && pass > 0) {   // column `pass` of uref <- previous answer (mpc_sim.py:296-299 after :302)
 #pragma unroll
@@ -143,8 +144,10 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
         // tolerances: it certifies its own answer, and a stalled iterate usually has the set
         const bool polished = polish<ALL>(s, fb, skip);
         if (!skip && polished) status = MPCX_ST_OK;
+        if (!skip && status == MPCX_ST_INACCURATE) inaccurate = true;
         if (!skip && status == MPCX_ST_FAILED) skip = true;
     }
+    if (status == MPCX_ST_OK && inaccurate) status = MPCX_ST_INACCURATE;
 
     // controls, predicted states (the linearised dynamics re-evaluated stage by stage),
     // objective = the cost expression of mpc_diff_drive.py:178-193 plus the difference term
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(256) void k_advance(mpcx_variant v, int64_t B, doub
                                                  const int32_t *__restrict__ target_ind,
                                                  const int32_t *__restrict__ course_id,
                                                  const double *__restrict__ cx, const double *__restrict__ cy,
-                                                 const int32_t *__restrict__ clen, int64_t Lmax,
+                                                 const int32_t *__restrict__ clen, int64_t n_courses, int64_t Lmax,
                                                  double *__restrict__ state, double *__restrict__ twist,
                                                  uint8_t *__restrict__ has_prev, uint8_t *__restrict__ done,
                                                  int32_t *__restrict__ ticks, double *__restrict__ log_out)
@@ -932,10 +935,13 @@ __global__ __launch_bounds__(256) void k_advance(mpcx_variant v, int64_t B, doub
         }
         has_prev[b] = solved ? 1 : 0;
         ticks[b] += 1;
+        // a course id outside the table, or a course the builder rejected (clen = -1) or that
+        // claims more points than a row holds, counts as a lost reference window
         const int64_t course = course_id ? course_id[b] : 0;
-        const int len = clen[course];
+        const bool known = course >= 0 && course < n_courses;
+        const int len = known ? clen[course] : 0;
         const int tind = target_ind[b];
-        if (tind < 0) {
+        if (tind < 0 || len < 1 || (int64_t)len > Lmax) {
             done[b] = 2;
         } else {
             const double dx = x - cx[course * Lmax + len - 1], dy = y - cy[course * Lmax + len - 1];
@@ -955,24 +961,30 @@ constexpr int kGroup = 16;
 __global__ __launch_bounds__(256) void k_nearest_ref(int mode, int T, double dt, double param, int n_search,
                                                      int sign, int64_t B, const double *__restrict__ state,
                                                      const int32_t *__restrict__ course_id,
-                                                     const int32_t *__restrict__ pind_in,
+                                                     const int32_t *pind_in,   // may be the same buffer as ind_out
                                                      const double *__restrict__ cx, const double *__restrict__ cy,
                                                      const double *__restrict__ cyaw,
-                                                     const int32_t *__restrict__ clen, int64_t Lmax,
-                                                     int32_t *__restrict__ ind_out, double *__restrict__ mind_out,
+                                                     const int32_t *__restrict__ clen, int64_t n_courses, int64_t Lmax,
+                                                     int32_t *ind_out, double *__restrict__ mind_out,
                                                      double *__restrict__ xref_out)
 {
     const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
     const int k = threadIdx.x % kGroup;
     const bool live = gid < B;
     const int64_t b = live ? gid : B - 1;
-    const int64_t course = course_id ? course_id[b] : 0;
+    // a course id outside the table, or a course whose length is not 1..Lmax (the builder marks
+    // a rejected course with -1), is searched as an empty window
+    int64_t course = course_id ? course_id[b] : 0;
+    const bool known = course >= 0 && course < n_courses;
+    if (!known) course = 0;
     const double *tx = cx + course * Lmax, *ty = cy + course * Lmax, *tw = cyaw + course * Lmax;
-    const int len = clen[course];
+    int len = known ? clen[course] : 0;
+    if (len < 0 || (int64_t)len > Lmax) len = 0;
     const int pind = pind_in[b];
     const double x = state[4 * b], y = state[4 * b + 1];
     const int lo = pind < len ? pind : len;
-    const int hi = pind + n_search < len ? pind + n_search : len;
+    const int64_t end = (int64_t)pind + n_search;
+    const int hi = end < len ? (int)end : len;
     double best = kBig;
     int bi = 0x7fffffff;
     for (int j = lo + k; j < hi; j += kGroup) {
@@ -1054,6 +1066,11 @@ static int hip_fail(hipError_t e, const char *what)
 {
     return fail(MPCX_E_HIP, "%s: %s", what, hipGetErrorString(e));
 }
+
+// hipGetLastError() also returns (and clears) an error left behind by an unrelated earlier HIP
+// call of the process; drop such a leftover before a launch so that the check after it reports
+// this launch only.
+static void clear_stale_error() { (void)hipGetLastError(); }
 
 static int check_variant(const mpcx_variant *v)
 {
@@ -1147,12 +1164,43 @@ static SolvePath choose_path(const mpcx_variant *v, int64_t B, bool chained)
     return kPathStage;
 }
 
+// The stage-wise kernel over a batch, `chunk` instances (a multiple of 64) per launch, every
+// launch using the same workspace `ws` (launches on one stream run one after the other).
+static int launch_stage_chunks(const SolveArgs &a, hipStream_t st, double *ws, int64_t chunk)
+{
+    const mpcx_variant *v = &a.v;
+    const int NU = v->nu, T = v->T, W = T + 1;
+    const int m = v->model == MPCX_MODEL_DIFF_DRIVE ? 0 : 1;
+    const dim3 block(kWave);
+    for (int64_t off = 0; off < a.B; off += chunk) {
+        SolveArgs c = a;
+        c.B = a.B - off < chunk ? a.B - off : chunk;
+        c.x0 = a.x0 + off * 3;
+        c.xref = a.xref + off * 3 * W;
+        if (a.xbar) c.xbar = a.xbar + off * 3 * W;
+        if (a.uin) c.uin = a.uin + off * NU * T;
+        if (a.has_prev) c.has_prev = a.has_prev + off;
+        c.u_out = a.u_out + off * NU * T;
+        c.x_out = a.x_out + off * 3 * W;
+        c.obj_out = a.obj_out + off;
+        c.status_out = a.status_out + off;
+        if (a.iters_out) c.iters_out = a.iters_out + off;
+        const dim3 grid((unsigned)((c.B + kWave - 1) / kWave));
+        if (m == 0) hipLaunchKernelGGL((k_solve_stage<0>), grid, block, 0, st, c, ws);
+        else hipLaunchKernelGGL((k_solve_stage<1>), grid, block, 0, st, c, ws);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "k_solve_stage launch");
+    }
+    return 0;
+}
+
 static int launch_solve(const SolveArgs &a, hipStream_t st)
 {
     const mpcx_variant *v = &a.v;
     if (a.B == 0) return 0;
     const bool chained = !a.linear_mode && v->chain > 1;
     const dim3 block(kWave);
+    clear_stale_error();
     const int m = v->model == MPCX_MODEL_DIFF_DRIVE ? 0 : 1;
     switch (choose_path(v, a.B, chained)) {
     case kPathPair5: {
@@ -1202,14 +1250,14 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
     case kPathStage:
         break;
     }
-    // stage-wise kernel: per-lane arrays in a workspace, launches chunked so that it stays bounded
+    // stage-wise kernel: per-lane arrays in a workspace
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
     if (dev < 0 || dev >= 64) return fail(MPCX_E_UNSUPPORTED, "device index %d", dev);
-    const int NU = v->nu, T = v->T, W = T + 1;
+    // launches chunked so that the grow-only buffer stays bounded
     const int64_t chunk = stage_chunk(a.B);
-    const size_t need = (size_t)stage_doubles_per_instance(T) * (size_t)chunk * sizeof(double);
+    const size_t need = (size_t)stage_doubles_per_instance(v->T) * (size_t)chunk * sizeof(double);
     std::lock_guard<std::mutex> lock(g_ws_mutex);
     if (g_ws_bytes[dev] < need) {
         if (g_ws[dev]) {
@@ -1231,25 +1279,7 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
         e = hipStreamWaitEvent(st, g_ws_event[dev], 0);
         if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
     }
-    for (int64_t off = 0; off < a.B; off += chunk) {
-        SolveArgs c = a;
-        c.B = a.B - off < chunk ? a.B - off : chunk;
-        c.x0 = a.x0 + off * 3;
-        c.xref = a.xref + off * 3 * W;
-        if (a.xbar) c.xbar = a.xbar + off * 3 * W;
-        if (a.uin) c.uin = a.uin + off * NU * T;
-        if (a.has_prev) c.has_prev = a.has_prev + off;
-        c.u_out = a.u_out + off * NU * T;
-        c.x_out = a.x_out + off * 3 * W;
-        c.obj_out = a.obj_out + off;
-        c.status_out = a.status_out + off;
-        if (a.iters_out) c.iters_out = a.iters_out + off;
-        const dim3 grid((unsigned)((c.B + kWave - 1) / kWave));
-        if (m == 0) hipLaunchKernelGGL((k_solve_stage<0>), grid, block, 0, st, c, g_ws[dev]);
-        else hipLaunchKernelGGL((k_solve_stage<1>), grid, block, 0, st, c, g_ws[dev]);
-        e = hipGetLastError();
-        if (e != hipSuccess) return hip_fail(e, "k_solve_stage launch");
-    }
+    if (int rc = launch_stage_chunks(a, st, g_ws[dev], chunk)) return rc;
     e = hipEventRecord(g_ws_event[dev], st);
     if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
     g_ws_event_set[dev] = true;
@@ -1377,6 +1407,7 @@ int mpcx_rollout_batch(const mpcx_variant *v, int64_t B, const double *x0, const
     if (B == 0) return 0;
     if (!x0 || !u || !xbar) return fail(MPCX_E_ARG, "NULL buffer");
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    clear_stale_error();
     if (v->model == MPCX_MODEL_DIFF_DRIVE)
         hipLaunchKernelGGL((k_rollout<0>), grid, block, 0, (hipStream_t)stream, *v, B, x0, u, xbar);
     else
@@ -1394,6 +1425,7 @@ int mpcx_linearize_batch(const mpcx_variant *v, int64_t B, const double *theta, 
     if (B == 0) return 0;
     if (!theta || !u || !A || !Bm || !C) return fail(MPCX_E_ARG, "NULL buffer");
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    clear_stale_error();
     if (v->model == MPCX_MODEL_DIFF_DRIVE)
         hipLaunchKernelGGL((k_linearize<0>), grid, block, 0, (hipStream_t)stream, *v, B, theta, u, A, Bm, C);
     else
@@ -1418,8 +1450,9 @@ int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int
     if (!state || !pind || !cx || !cy || !cyaw || !clen || !ind_out) return fail(MPCX_E_ARG, "NULL buffer");
     const int64_t threads = B * kGroup;
     const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    clear_stale_error();
     hipLaunchKernelGGL(k_nearest_ref, grid, block, 0, (hipStream_t)stream, mode, T, dt, param, n_search, sign, B,
-                       state, course_id, pind, cx, cy, cyaw, clen, Lmax, ind_out, mind_out, xref_out);
+                       state, course_id, pind, cx, cy, cyaw, clen, n_courses, Lmax, ind_out, mind_out, xref_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "k_nearest_ref launch");
 }
@@ -1437,13 +1470,14 @@ int mpcx_advance_batch(const mpcx_variant *v, int64_t B, double goal_dis, double
     if (!u || !status || !target_ind || !cx || !cy || !clen || !state || !has_prev || !done || !ticks)
         return fail(MPCX_E_ARG, "NULL buffer");
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    clear_stale_error();
     if (v->model == MPCX_MODEL_DIFF_DRIVE)
         hipLaunchKernelGGL(k_advance<MPCX_MODEL_DIFF_DRIVE>, grid, block, 0, (hipStream_t)stream, *v, B, goal_dis,
-                           stop_speed, u, status, target_ind, course_id, cx, cy, clen, Lmax, state, twist, has_prev,
+                           stop_speed, u, status, target_ind, course_id, cx, cy, clen, n_courses, Lmax, state, twist, has_prev,
                            done, ticks, log_out);
     else
         hipLaunchKernelGGL(k_advance<MPCX_MODEL_DSR>, grid, block, 0, (hipStream_t)stream, *v, B, goal_dis,
-                           stop_speed, u, status, target_ind, course_id, cx, cy, clen, Lmax, state, twist, has_prev,
+                           stop_speed, u, status, target_ind, course_id, cx, cy, clen, n_courses, Lmax, state, twist, has_prev,
                            done, ticks, log_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "k_advance launch");
@@ -1458,6 +1492,7 @@ int mpcx_build_courses_batch(int64_t K, int32_t n_way_max, const double *wx, con
     if (!(ds > 0.0) || Lmax < 1) return fail(MPCX_E_ARG, "ds must be positive and Lmax >= 1");
     if (K == 0) return 0;
     if (!wx || !wy || !nway || !cx || !cy || !cyaw || !clen) return fail(MPCX_E_ARG, "NULL buffer");
+    clear_stale_error();
     hipLaunchKernelGGL(k_build_courses, dim3((unsigned)K), dim3(kWave), 0, (hipStream_t)stream, K, (int)n_way_max, wx, wy,
                        nway, ds, Lmax, (int)smooth, cx, cy, cyaw, ck, clen);
     hipError_t e = hipGetLastError();

@@ -64,9 +64,10 @@ def solve_batch(v: CVariant, x0, xref, uprev=None, has_prev=None, out=None) -> D
             raise ValueError("has_prev must be [B]")
     if out is None:
         out = _outputs(B, NU, T, x0.device)
-    _lib.check(lib.mpcx_solve_batch(C.byref(v), B, _ptr(x0), _ptr(xref), _ptr(uprev), _ptr(has_prev),
-                                    _ptr(out["u"]), _ptr(out["x"]), _ptr(out["obj"]), _ptr(out["status"]),
-                                    _ptr(out["iters"]), _stream()))
+    entry = lib.mpcx_solve_batch
+    _lib.check(entry(C.byref(v), B, _ptr(x0), _ptr(xref), _ptr(uprev), _ptr(has_prev),
+                     _ptr(out["u"]), _ptr(out["x"]), _ptr(out["obj"]), _ptr(out["status"]),
+                     _ptr(out["iters"]), _stream()))
     return out
 
 
@@ -311,6 +312,10 @@ class ClosedLoop:
         in a captured loop.  Capturing itself advances the loop by two (warm-up) ticks."""
         if self.log is not None:
             raise _lib.MpcxError("a logging loop cannot be captured: the log slot changes every tick")
+        need = self.lib.mpcx_workspace_bytes(C.byref(self.v), self.B)
+        if need != 0:
+            raise _lib.MpcxError(f"this loop's solve takes the workspace path ({need} bytes): it allocates and "
+                                 "waits on an event, which a stream capture does not allow")
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -96,3 +96,16 @@ def test_graph_replay_equals_eager_ticks():
     for name in ("state", "twist", "target_ind", "done", "ticks", "has_prev"):
         np.testing.assert_array_equal(getattr(graph, name).cpu().numpy(), getattr(eager, name).cpu().numpy())
     np.testing.assert_array_equal(graph.last_u.cpu().numpy(), eager.last_u.cpu().numpy())
+
+
+def test_capture_of_a_workspace_loop_is_refused():
+    """A loop whose solve takes the workspace path (T = 30 beyond the chip-resident batch) would
+    allocate and wait on an event inside the capture: capture() must refuse it up front."""
+    from model_predictive_control_amd import _lib
+    engine, v, ov, table, tabs, state, cid, pind = _setup("dsr_ackermann", 2000, 33, T=30)
+    loop = engine.ClosedLoop(v, table, state, cid, pind0=pind)
+    with pytest.raises(_lib.MpcxError, match="workspace"):
+        loop.capture()
+    loop.run(1)
+    torch.cuda.synchronize()
+    assert (loop.out["status"].cpu().numpy() <= 1).mean() > 0.99 or (loop.uprev.abs().sum() > 0)

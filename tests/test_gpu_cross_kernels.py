@@ -46,6 +46,7 @@ def test_alternative_kernels_agree(tmp_path, name, T, B, hooks):
     a = _run(hooks[0], name, B, T, str(tmp_path / "a.npz"))
     b = _run(hooks[1], name, B, T, str(tmp_path / "b.npz"))
     for st in ("status", "status2"):
+        assert np.array_equal(a[st], b[st])
         assert (a[st] == 0).all() and (b[st] == 0).all()
     tol = 1e-6 if name.startswith("sim_") else 1e-9      # five chained QPs amplify the last digits
     assert np.abs(a["u"] - b["u"]).max() <= tol

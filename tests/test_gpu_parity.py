@@ -120,6 +120,50 @@ def test_nearest_with_a_non_finite_position(eng, golden):
     assert np.isnan(mind.cpu().numpy()[0]) and np.isnan(wm[0])
 
 
+def test_bad_course_ids_and_rejected_courses_are_empty_windows(eng, golden):
+    """A course id outside the table, a course the builder rejected (clen = -1) and one claiming
+    more points than a table row holds are searched as empty windows (ind = -1, NaN window),
+    never read out of bounds; `ind_out` may be the buffer `pind` came in."""
+    import torch
+    tab = _course_table(eng, golden)
+    clen = tab.clen_host.copy()
+    clen[1], clen[2] = -1, tab.Lmax + 5
+    tab.clen = torch.from_numpy(clen).cuda()
+    state = np.tile(np.array([[1.0, 2.0, 0.0, 0.1]]), (6, 1))
+    cid = np.array([0, 1, 2, 7, -3, 3], np.int32)
+    pind = np.array([4, 4, 4, 4, 4, 4], np.int32)
+    ind, mind, xr = eng.nearest_ref_batch(1, 5, 0.2, 2, state, cid, pind, tab)
+    ind, xr = ind.cpu().numpy(), xr.cpu().numpy()
+    assert ind[0] >= 4 and ind[5] >= 4 and np.isfinite(xr[[0, 5]]).all()
+    assert (ind[1:5] == -1).all() and np.isnan(xr[1:5]).all() and np.isnan(mind.cpu().numpy()[1:5]).all()
+    # the closed-loop step freezes such vehicles as "window lost"
+    from model_predictive_control_amd import _lib, variants
+    import ctypes as C
+    v = variants.get("dsr_ackermann")
+    lib = _lib.load()
+    B = 6
+    u = torch.zeros((B, 4, 5), dtype=torch.float64, device="cuda")
+    status = torch.zeros(B, dtype=torch.int32, device="cuda")
+    tind = torch.full((B,), 4, dtype=torch.int32, device="cuda")
+    d_state = torch.from_numpy(state).cuda()
+    has_prev = torch.zeros(B, dtype=torch.uint8, device="cuda"); done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    ticks = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_cid = torch.from_numpy(cid).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.mpcx_advance_batch(C.byref(v), B, 1.5, 0.1, p(u), p(status), p(tind), p(d_cid), p(tab.cx), p(tab.cy),
+                                      p(tab.clen), tab.K, tab.Lmax, p(d_state), None, p(has_prev), p(done), p(ticks), None,
+                                      None))
+    torch.cuda.synchronize()
+    assert done.cpu().numpy().tolist() == [0, 2, 2, 2, 2, 0]
+    # in place: pind and ind_out the same buffer
+    d_pind = torch.from_numpy(pind).cuda()
+    d_state4 = torch.from_numpy(state).cuda()
+    _lib.check(lib.mpcx_nearest_ref_batch(1, 5, 0.2, 2.0, 10, 1, B, p(d_state4), p(d_cid), p(d_pind), p(tab.cx), p(tab.cy),
+                                          p(tab.cyaw), p(tab.clen), tab.K, tab.Lmax, p(d_pind), None, None, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pind.cpu().numpy(), ind)
+
+
 # ------------------------------------------------------------------------------- QP solve
 
 @pytest.mark.parametrize("name", T5_VARIANTS)
