@@ -107,6 +107,20 @@ int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const d
                      const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,
                      double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream);
 
+/* No counterpart in the reference: mpcx_solve_batch for callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * Same arguments, same kernels, same results; the call allocates and frees nothing, creates no
+ * event and never synchronises.  Where the solve needs a workspace (see mpcx_workspace_bytes)
+ * it uses a fixed array of mpcx_static_workspace_bytes() bytes that lives in the library's
+ * device image on every GPU; a batch whose workspace (472 T bytes per instance, B rounded up
+ * to a multiple of 64) exceeds it is rejected with MPCX_E_NOMEM and nothing is launched.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different
+ * streams, or different host threads) race; calls on one stream are safe. */
+int mpcx_solve_batch_noalloc(const mpcx_variant *v, int64_t B, const double *x0, const double *xref,
+                             const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,
+                             double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream);
+int64_t mpcx_static_workspace_bytes(void);
+
 /* linear_mpc_control (mpc_diff_drive.py:170-217), linear_mpc_control_{ackermann,crab,diff}
  * (mpc_dsr.py:201-395), MPC.doLMPC_* (mpc_sim.py:312-508), controlLaw (mpc.py:117-187):
  * one QP at the given linearisation point (xbar, uref). */

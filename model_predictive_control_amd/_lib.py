@@ -44,6 +44,8 @@ SIGNATURES = {
     "mpcx_variant_by_name": (C.c_int, [C.c_char_p, C.POINTER(CVariant)]),
     "mpcx_workspace_bytes": (C.c_int64, [C.POINTER(CVariant), C.c_int64]),
     "mpcx_solve_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
+    "mpcx_solve_batch_noalloc": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
+    "mpcx_static_workspace_bytes": (C.c_int64, []),
     "mpcx_linear_mpc_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
     "mpcx_rollout_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD]),
     "mpcx_linearize_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD]),

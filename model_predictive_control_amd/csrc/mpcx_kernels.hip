@@ -1194,7 +1194,30 @@ static int launch_stage_chunks(const SolveArgs &a, hipStream_t st, double *ws, i
     return 0;
 }
 
-static int launch_solve(const SolveArgs &a, hipStream_t st)
+// Workspace of the entry point that allocates nothing: a fixed array in the library's own
+// device image (every GPU the library runs on holds its copy from the moment the code object is
+// loaded until the process ends).  In host code the array's name is only a handle for
+// hipGetSymbolAddress: the address kernels and memsets are given is looked up once per device,
+// with that device current, and kept.
+constexpr size_t kScratchBytes = (size_t)64 << 20;
+static __device__ __align__(256) double scratch[kScratchBytes / sizeof(double)];
+static double *g_scratch_ptr[64] = {nullptr};
+static std::mutex g_scratch_mutex;
+
+static int scratch_of_device(int dev, double **out)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));   // the current device's copy
+        if (e != hipSuccess || !p) return hip_fail(e, "hipGetSymbolAddress(scratch)");
+        g_scratch_ptr[dev] = (double *)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace = false)
 {
     const mpcx_variant *v = &a.v;
     if (a.B == 0) return 0;
@@ -1255,6 +1278,19 @@ static int launch_solve(const SolveArgs &a, hipStream_t st)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
     if (dev < 0 || dev >= 64) return fail(MPCX_E_UNSUPPORTED, "device index %d", dev);
+    if (fixed_workspace) {
+        // the caller may not allocate: the library's own fixed array, one launch, no event
+        const int64_t slots = ((a.B + kWave - 1) / kWave) * kWave;
+        const size_t need = (size_t)stage_doubles_per_instance(v->T) * (size_t)slots * sizeof(double);
+        if (need > kScratchBytes)
+            return fail(MPCX_E_NOMEM, "%lld instances at T=%d need %zu bytes of workspace; the entry point that "
+                        "allocates nothing holds %zu (at most %lld instances at this horizon)", (long long)a.B, v->T,
+                        need, kScratchBytes,
+                        (long long)(kScratchBytes / ((size_t)stage_doubles_per_instance(v->T) * sizeof(double)) / kWave * kWave));
+        double *ws = nullptr;
+        if (int rc = scratch_of_device(dev, &ws)) return rc;
+        return launch_stage_chunks(a, st, ws, slots);
+    }
     // launches chunked so that the grow-only buffer stays bounded
     const int64_t chunk = stage_chunk(a.B);
     const size_t need = (size_t)stage_doubles_per_instance(v->T) * (size_t)chunk * sizeof(double);
@@ -1378,6 +1414,26 @@ int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const d
     a.linear_mode = 0;
     a.max_iter = 60;
     return launch_solve(a, (hipStream_t)stream);
+}
+
+int64_t mpcx_static_workspace_bytes(void) { return (int64_t)kScratchBytes; }
+
+int mpcx_solve_batch_noalloc(const mpcx_variant *v, int64_t B, const double *x0, const double *xref,
+                             const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,
+                             double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream)
+{
+    int rc = check_variant(v);
+    if (rc) return rc;
+    if (B < 0) return fail(MPCX_E_ARG, "negative batch");
+    if (B > 0 && (!x0 || !xref || !u_out || !x_out || !obj_out || !status_out))
+        return fail(MPCX_E_ARG, "NULL buffer");
+    SolveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.v = *v; a.B = B; a.x0 = x0; a.xref = xref; a.xbar = nullptr; a.uin = uprev; a.has_prev = has_prev;
+    a.u_out = u_out; a.x_out = x_out; a.obj_out = obj_out; a.status_out = status_out; a.iters_out = iters_out;
+    a.linear_mode = 0;
+    a.max_iter = 60;
+    return launch_solve(a, (hipStream_t)stream, true);
 }
 
 int mpcx_linear_mpc_batch(const mpcx_variant *v, int64_t B, const double *xref, const double *xbar,

@@ -45,9 +45,10 @@ def _outputs(B: int, NU: int, T: int, dev) -> Dict[str, torch.Tensor]:
                 iters=torch.empty((B,), dtype=torch.int32, device=dev))
 
 
-def solve_batch(v: CVariant, x0, xref, uprev=None, has_prev=None, out=None) -> Dict[str, torch.Tensor]:
+def solve_batch(v: CVariant, x0, xref, uprev=None, has_prev=None, out=None, noalloc: bool = False) -> Dict[str, torch.Tensor]:
     """iterative_linear_mpc_control for B instances: x0 [B,3], xref [B,3,T+1],
-    uprev [B,NU,T] or None (cold start), has_prev [B] uint8 or None."""
+    uprev [B,NU,T] or None (cold start), has_prev [B] uint8 or None.  `noalloc` (with `out`
+    given and device tensors in) goes through the entry point that allocates nothing."""
     lib = _lib.load()
     x0 = _dev(x0)
     xref = _dev(xref)
@@ -64,7 +65,7 @@ def solve_batch(v: CVariant, x0, xref, uprev=None, has_prev=None, out=None) -> D
             raise ValueError("has_prev must be [B]")
     if out is None:
         out = _outputs(B, NU, T, x0.device)
-    entry = lib.mpcx_solve_batch
+    entry = lib.mpcx_solve_batch_noalloc if noalloc else lib.mpcx_solve_batch
     _lib.check(entry(C.byref(v), B, _ptr(x0), _ptr(xref), _ptr(uprev), _ptr(has_prev),
                      _ptr(out["u"]), _ptr(out["x"]), _ptr(out["obj"]), _ptr(out["status"]),
                      _ptr(out["iters"]), _stream()))
