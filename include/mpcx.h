@@ -89,7 +89,7 @@ int mpcx_variant_by_name(const char *name, mpcx_variant *out);
 /* Bytes of device workspace mpcx_solve_batch / mpcx_linear_mpc_batch need for B
  * instances of this variant: 0 for the kernels that live in registers and LDS (T = 5,
  * T = 10, and batches up to T = 32 that the chip holds at once), otherwise the per-lane
- * arrays of the stage-wise kernel for one launch (472 T bytes per instance, at most
+ * arrays of the stage-wise kernel for one launch (440 T bytes per instance, at most
  * 262,144 instances per launch).  The library keeps one grow-only buffer per device for
  * it; calls that need it are serialised per device (each waits on the device for the
  * previous one, whatever its stream), the first one allocates, and none of them may be
@@ -112,7 +112,7 @@ int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const d
  * Same arguments, same kernels, same results; the call allocates and frees nothing, creates no
  * event and never synchronises.  Where the solve needs a workspace (see mpcx_workspace_bytes)
  * it uses a fixed array of mpcx_static_workspace_bytes() bytes that lives in the library's
- * device image on every GPU; a batch whose workspace (472 T bytes per instance, B rounded up
+ * device image on every GPU; a batch whose workspace (440 T bytes per instance, B rounded up
  * to a multiple of 64) exceeds it is rejected with MPCX_E_NOMEM and nothing is launched.
  * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different
  * streams, or different host threads) race; calls on one stream are safe. */

@@ -42,6 +42,11 @@ constexpr double kMuFloor = 1e-13;    // below this the recomputed slacks are ro
 constexpr double kLooseD = 1e-6;      // "inaccurate but accepted" thresholds
 constexpr double kLooseMu = 1e-7;
 constexpr double kEtaCap = 0.999;
+#ifndef MPCX_SWITCH_MU
+#define MPCX_SWITCH_MU 1e-5
+#endif
+constexpr double kSwitchMu = MPCX_SWITCH_MU;   // stage-wise kernel: complementarity at which the active set is read off the interior point
+constexpr double kSwitchD = 1e-3;     // ... and the relative dual residual it asks for
 constexpr double kMinWidth = 2e-9;    // a first-stage window narrower than this is widened to it
 constexpr double kBig = 1e300;
 #ifndef MPCX_RHO_CAP

@@ -516,14 +516,15 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
 // ------------------------------------------------------------------------------------
 // solve: one instance per lane, stage-wise (Riccati) linear algebra, arrays in a workspace
 // ------------------------------------------------------------------------------------
-#ifndef MPCX_STAGE_K
-#define MPCX_STAGE_K 6
-#endif
 #ifndef MPCX_STAGE_R0
-#define MPCX_STAGE_R0 8
+#define MPCX_STAGE_R0 5
 #endif
-constexpr int kStageIpmIters = MPCX_STAGE_K;   // interior-point iterations before the active-set rounds
-constexpr int kStageRounds0 = MPCX_STAGE_R0, kStageRounds1 = 5;
+constexpr int kStageIpmCap = 40;   // interior-point iterations at most per attempt but the last
+constexpr int kStageAttempts = 3;
+// complementarity at which an attempt hands over to the active-set rounds (0: converged), and
+// the rounds it may take
+__device__ const double kStageSwitchMu[kStageAttempts] = {kSwitchMu, 1e-8, 0.0};
+__device__ const int kStageRounds[kStageAttempts] = {MPCX_STAGE_R0, 6, 6};
 
 template <int MODEL>
 __global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *ws)
@@ -626,28 +627,32 @@ __global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *w
         free_bounds(v, u0, p.fb);
         if (!p.fb.feasible && !skip) { skip = true; status = MPCX_ST_INFEASIBLE; }
         const double gmax = stagewise::gradient_at_zero(s, p);
-        // The start is the oracle's (complementarity 0.1).  A start in proportion to the gradient
-        // (0.1 * max |g|) was tried for the T = 30 fixed-steer variant, whose weights grow like
-        // 2^t: 62 ms -> 40 ms per 65,536 warm-started instances, but its optimum is so flat
-        // (cond 5e10) that a different path ends 5e-2 away in the controls at the same objective
-        // to 3e-12; the common start keeps the two solvers within 5e-5 of each other there.
-        p.mu0 = kMu0;
-        (void)gmax;
-        const double hmax = stagewise::hessian_scale(s, p);
-        int st = MPCX_ST_OK, it = 0;
+        // initial complementarity in proportion to the gradient: with weights that grow like 2^t
+        // (mpc_dsr.py:349) the gradient reaches 1e7, and from 0.1 the interior point spends 25
+        // iterations just raising its multipliers to that scale
+        p.mu0 = kMu0 * dmax(1.0, gmax);
+        // Attempts: the interior point down to a complementarity at which the active set can
+        // usually be read off the iterate, then the active-set rounds; a lane whose rounds do not
+        // settle lets the interior point run further (it continues, nothing is redone) and tries
+        // again, the last time from a converged iterate, whose own verdict stands if the rounds
+        // still fail.
+        int st = MPCX_ST_OK;
         const bool run = !skip;
-        stagewise::ipm(s, p, a.max_iter < kStageIpmIters ? a.max_iter : kStageIpmIters, true, run, st, it);
-        if (run) iters += it;
-        bool settled = stagewise::pdas(s, p, kStageRounds0, hmax, run);
-        const bool again = run && !settled;
-        if (__any(again)) {
-            stagewise::ipm(s, p, a.max_iter, false, again, st, it);
-            if (again) {
-                iters += it;
-                status = st;
-            }
-            if (stagewise::pdas(s, p, kStageRounds1, hmax, again)) settled = true;
+        bool settled = false, todo = run;
+        int spent = 0;
+        for (int attempt = 0; attempt < kStageAttempts; ++attempt) {
+            if (!__any(todo)) break;
+            int it = 0, used = 0;
+            const int cap = a.max_iter < kStageIpmCap || attempt + 1 == kStageAttempts ? a.max_iter : kStageIpmCap;
+            stagewise::ipm(s, p, cap, kStageSwitchMu[attempt], attempt > 0, todo, st, it);
+            if (todo) { iters += it; spent += it; status = st; }
+            const bool ok = stagewise::pdas(s, p, kStageRounds[attempt], todo, used);
+#ifdef MPCX_DIAG   // diagnostic builds report the rounds in the iteration count
+            if (todo) iters += (attempt == 0 ? 100 : 10000) * (used + (attempt == 0 ? 0 : 1));
+#endif
+            if (todo && ok) { settled = true; todo = false; }
         }
+        (void)spent;
         if (run) {
             if (settled) status = MPCX_ST_OK;
             if (status == MPCX_ST_INACCURATE) inaccurate = true;

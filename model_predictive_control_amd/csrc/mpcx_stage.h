@@ -12,9 +12,14 @@
 // Per-lane arrays (the iterate, the stage dynamics, the Riccati gains) live in a global
 // workspace, one contiguous chunk per wavefront laid out [stage][field][lane]: every access of
 // a wavefront is one contiguous 512-byte row and each sweep over the stages streams through the
-// chunk in address order.  The solver itself is the one the other kernels use: a fixed number of predictor-corrector interior-point iterations to find
-// the active set, primal-dual active-set rounds that certify the KKT conditions, and for
-// whatever does not settle a converged interior-point solve and the rounds again.
+// chunk in address order.  The solver: predictor-corrector interior-point iterations, started in
+// proportion to the gradient, until the complementarity is small enough to read the active set
+// off the iterate; then primal-dual active-set rounds in which the working set is eliminated
+// exactly (a control on its box is fixed, a control on a rate bound moves with the previous
+// stage's: both are affine policies the Riccati sweep carries), multipliers are recovered from
+// the true gradient by sums along the chains of tied stages, and a point is accepted on the KKT
+// conditions stage by stage, each residual measured against the rounding noise of the terms it
+// sums.  Whatever does not settle continues the interior point from where it stood and tries again.
 #pragma once
 #include "mpcx_device.h"
 
@@ -40,11 +45,12 @@ struct Store {
         fKv = 42,        // feed-forward of the current right-hand side
         fDwa = 44, fDw = 46,
         fBak = 48,       // controls before the active-set rounds
-        fSetB = 50,      // active-set flags of the boxes (1: upper, 2: lower)
-        fSetR = 52,      // ... of the rate constraints (t, t + 1), same coding
-        fUref = 54,      // linearisation point: controls and yaw (rewritten between chained solves)
-        fTheta = 58,
-        kFields = 59
+        fUref = 50,      // linearisation point: controls and yaw (rewritten between chained solves)
+        fTheta = 54,
+        kFields = 55,
+        // the rounds keep the gradient, the chain sum it hands to its left neighbour and the
+        // noise scale where the interior point keeps its steps
+        fGr = fDwa, fMag = fDw, fCur = fKv
     };
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t lane_bytes;
@@ -406,9 +412,12 @@ __device__ __forceinline__ void slacks(const Problem &p, int t, const double (&w
     }
 }
 
-// Predictor-corrector interior point on the lanes with `run` set.  `fixed`: exactly max_iter
-// iterations, no convergence test.  Otherwise status/iters as in the other kernels.
-__device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_iter, bool fixed, bool run,
+// Predictor-corrector interior point on the lanes with `run` set.  With mu_stop > 0 a lane
+// stops as soon as its complementarity is below mu_stop and its dual residual is small (the
+// active set can then be read off the iterate); otherwise it runs to convergence; at most
+// max_iter iterations either way.  `resume` continues from the stored iterate (controls and
+// multipliers as the previous call left them) instead of starting over.
+__device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_iter, double mu_stop, bool resume, bool run,
                                     int &status, int &iters)
 {
     const int T = s.T;
@@ -418,7 +427,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
             m += (p.hb(0, c) ? 2.0 : 0.0) + (T > 1 && p.hb(1, c) ? 2.0 * (T - 1) : 0.0) + (p.hr(c) ? 2.0 * (T - 1) : 0.0);
         return m > 0.0 ? 1.0 / m : 0.0;
     }();
-    if (run) {
+    if (run && !resume) {
         // strictly feasible start: every stage at the middle of its channel's first-stage window
         double wc[2];
 #pragma unroll
@@ -494,10 +503,6 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         pend = false;
     };
     for (int it = 0;; ++it) {
-        if (fixed && it >= max_iter) {
-            if (run) iters = it;
-            break;
-        }
         if (!__any(run)) break;
         update_and_roll(true);
         // backward: gradient, residuals, Riccati gains, feed-forward of the predictor (r = -hw)
@@ -554,9 +559,14 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         }
         const double mu = musum * inv_m;
         const double scale = dmax(1.0, scl) + 1.0;
-        if (!fixed && run) {
+        if (run) {
             const bool conv = rdmax <= kTolD * scale && mu <= kTolMu;
             if (conv) { status = MPCX_ST_OK; iters = it; run = false; }
+            else if (mu_stop > 0.0 && mu <= mu_stop && rdmax <= kSwitchD * scale) {
+                iters = it;
+                status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
+                run = false;
+            }
             else if (mu < kMuFloor || it >= max_iter || !finite_d(mu + rdmax)) {
                 iters = it;
                 status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
@@ -680,19 +690,371 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
 }
 
 // ------------------------------------------------------------------------------------
-// primal-dual active-set rounds
+// primal-dual active-set rounds with the working set eliminated exactly
 // ------------------------------------------------------------------------------------
-// Starts from the interior-point iterate on the lanes with `run`; returns true where the
-// point is certified (then w holds it), otherwise w is put back as it was.
-__device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_rounds, double hmax, bool run)
+// The working set, one bit per stage (T <= 64): bu/bl the upper/lower box of stage t, ru/rl the
+// rate constraint between stages t and t + 1 at +rr / -rr.
+struct Sets {
+    uint64_t bu[2], bl[2], ru[2], rl[2];
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bu[c] = bl[c] = ru[c] = rl[c] = 0;
+    }
+};
+__device__ __forceinline__ bool bit(uint64_t m, int t) { return ((m >> t) & 1ull) != 0; }
+__device__ __forceinline__ uint64_t one(int t) { return 1ull << t; }
+
+// Stages whose control is determined by the working set alone: on a box, or tied to such a
+// stage further on (fixedR_t = box_t or (tie_t and fixedR_{t+1})).
+__device__ __forceinline__ uint64_t fixed_from_right(uint64_t box, uint64_t tie, int T)
+{
+    uint64_t f = 0;
+    bool nxt = false;
+    for (int t = T - 1; t >= 0; --t) {
+        const bool cur = bit(box, t) || (bit(tie, t) && nxt);
+        if (cur) f |= one(t);
+        nxt = cur;
+    }
+    return f;
+}
+
+#ifndef MPCX_NOISE_TOL
+#define MPCX_NOISE_TOL 5e-14
+#endif
+constexpr double kNoiseTol = MPCX_NOISE_TOL;   // KKT residuals are accepted below this multiple of (1 + the summed magnitudes)
+constexpr double kFeasTol = 1e-12;    // constraint violation that enters the working set
+
+// Backward sweep at the stored controls: the true gradient gr_t = (H w + g)_t by the adjoint of
+// the rollout, the size mag_t of the terms it sums (x - xref cancels, so its rounding error is
+// relative to |x| + |xref| <= |x - xref| + 2 |xref|), and for every rate constraint whose later
+// stage moves with the earlier one the multiplier nu_t = nu_{t+1} - gr_{t+1} (stationarity of
+// that later stage); a multiplier of the wrong sign is marked in `drop`.  Stores gr, the chain
+// term cur_t = nu_t of such a constraint (else 0) and mag per stage.
+__device__ __forceinline__ void rounds_adjoint(const Store &s, const Problem &p, const Sets &S, const uint64_t (&fixedR)[2],
+                                               Sets &drop)
 {
     const int T = s.T;
-    // penalty of the augmented Lagrangian: 1e5 times the curvature scale, capped where weights that
-    // grow like 2^t would push it to 1e14 and the Newton step of the rounds into rounding noise
-    // (T = 30 fixed-steer variant: agreement with the oracle 5e-5 -> 2e-7 in the controls)
-    const double rho = dmin(1e5 * hmax, kRhoCap);
+    double lam[3] = {0.0, 0.0, 0.0}, la[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0;
+    double wn[2] = {0.0, 0.0}, curn[2] = {0.0, 0.0}, grn[2] = {0.0, 0.0}, magn[2] = {0.0, 0.0};
+    double qg = 1.0;
+    for (int t = 1; t < T; ++t) qg *= p.growth;        // growth^(T - 1)
+    double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
+    _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
+        Dyn d;
+        load_dyn(s, t, d);
+        // adjoint and the size of its terms
+        {
+            const double l2 = fma(a02n, lam[0], fma(a12n, lam[1], lam[2]));
+            const double m2 = fma(fabs(a02n), la[0], fma(fabs(a12n), la[1], la[2]));
+            double qe[3], qa[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                qe[r] = s.ld(s.f(s.fQe + r, t));
+                const double q = t + 1 < T ? p.q[r] * qg * p.growth : p.qf[r];
+                qa[r] = fabs(qe[r]) + 4.0 * q * fabs(s.ld(s.f(s.fXr + r, t)));
+            }
+            lam[0] += qe[0]; lam[1] += qe[1]; lam[2] = l2 + qe[2];
+            la[0] += qa[0]; la[1] += qa[1]; la[2] = m2 + qa[2];
+        }
+        double wp[2] = {0.0, 0.0};
+        if (t > 0) { wp[0] = s.ld(s.p(s.fW, t - 1, 0)); wp[1] = s.ld(s.p(s.fW, t - 1, 1)); }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double gr = input_cost_grad(p, c, t, T, wp[c], wc[c], wn[c])
+                              + fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
+            double mag = fabs(2.0 * p.rw[c] * wc[c]) + fma(fabs(d.b[0][c]), la[0], fma(fabs(d.b[1][c]), la[1], fabs(d.b[2][c]) * la[2]));
+            if (t > 0) mag += fabs(2.0 * p.rdw[c] * (wc[c] - wp[c]));
+            if (t + 1 < T) mag += fabs(2.0 * p.rdw[c] * (wn[c] - wc[c]));
+            const bool up = bit(S.ru[c], t), dn = bit(S.rl[c], t);
+            double cur = 0.0;
+            if ((up || dn) && !bit(fixedR[c], t + 1)) {
+                cur = curn[c] - grn[c];
+                const double tol = kNoiseTol * (dmax(mag, magn[c]) + 1.0);
+                if (up && cur < -tol) drop.ru[c] |= one(t);
+                if (dn && -cur < -tol) drop.rl[c] |= one(t);
+            }
+            s.st(s.p(s.fGr, t, c), gr);
+            s.st(s.p(s.fCur, t, c), cur);
+            s.st(s.p(s.fMag, t, c), mag);
+            curn[c] = cur; grn[c] = gr; magn[c] = mag;
+            wn[c] = wc[c];
+            wc[c] = wp[c];
+        }
+        a02n = d.a02; a12n = d.a12;
+        qg = qg / p.growth;
+    }
+}
+
+// Forward pass over what rounds_adjoint stored: the remaining multipliers from
+// gr_t + mu_t + nu_{t-1} - nu_t = 0 (mu the box multiplier of stage t, nu_t the multiplier of
+// the rate constraint (t, t + 1)).  Along a chain of stages tied to a fixed one the sums run
+// forward, nu_t = gr_t + mu_t + nu_{t-1}, and a box at the end of the chain takes what is left.
+// A chain that also passes over boxes (a steer that zigzags between its box and one rate step
+// off it: the box is a whole number of rate steps wide) has one constraint more than controls,
+// so its multipliers are not unique: what is carried forward is the interval [flo, fhi] of the
+// values nu_{t-1} can take with every multiplier so far of the right sign, and the working set
+// passes if the interval never empties.  The constraint at which it does is marked in `drop`,
+// as is every uniquely determined multiplier of the wrong sign; returns whether every free
+// degree of freedom is stationary to rounding.
+__device__ __forceinline__ bool rounds_multipliers(const Store &s, const Sets &S, const uint64_t (&fixedR)[2], Sets &drop,
+                                                   double &check)
+{
+    const int T = s.T;
+    bool stat_ok = true;
+    double flo[2] = {0.0, 0.0}, fhi[2] = {0.0, 0.0}, magp[2] = {0.0, 0.0};
+    _Pragma("nounroll") for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double gr = s.ld(s.p(s.fGr, t, c)), cur = s.ld(s.p(s.fCur, t, c)), mag = s.ld(s.p(s.fMag, t, c));
+            check += gr + cur;
+            const bool fx = bit(fixedR[c], t);
+            const bool tie_prev = t > 0 && (bit(S.ru[c], t - 1) || bit(S.rl[c], t - 1));
+            const bool up = bit(S.ru[c], t), dn = bit(S.rl[c], t);
+            const bool bu = bit(S.bu[c], t), bl = bit(S.bl[c], t);
+            const bool chained = tie_prev && fx;          // nu_{t-1} comes along a fixed chain
+            const double plo = chained ? flo[c] : 0.0, phi = chained ? fhi[c] : 0.0;
+            const double tol = kNoiseTol * (dmax(mag, magp[c]) + 1.0);
+            double nlo = 0.0, nhi = 0.0;
+            if ((up || dn) && bit(fixedR[c], t + 1)) {
+                // nu_t = gr + mu_t + nu_{t-1}: mu_t >= 0 on an upper box, <= 0 on a lower one
+                nlo = bl ? -kBig : gr + plo;
+                nhi = bu ? kBig : gr + phi;
+                if (up) {
+                    if (nhi < -tol) { drop.ru[c] |= one(t); nlo = nhi = 0.0; }
+                    else { nlo = dmax(nlo, 0.0); nhi = dmax(nhi, nlo); }
+                } else {
+                    if (nlo > tol) { drop.rl[c] |= one(t); nlo = nhi = 0.0; }
+                    else { nhi = dmin(nhi, 0.0); nlo = dmin(nlo, nhi); }
+                }
+            } else if (bu || bl) {
+                // mu_t = -(gr - cur) - nu_{t-1} for some nu_{t-1} in [plo, phi]
+                const double need = -(gr - cur);
+                if (bu && need - plo < -tol) drop.bu[c] |= one(t);
+                if (bl && need - phi > tol) drop.bl[c] |= one(t);
+            } else if (!fx && !tie_prev) {
+                if (!(fabs(gr - cur) <= kNoiseTol * (mag + 1.0))) stat_ok = false;
+            }
+            flo[c] = nlo; fhi[c] = nhi;
+            magp[c] = mag;
+        }
+    }
+    return stat_ok;
+}
+
+// Backward Riccati sweep of the equality-constrained problem on the working set.  Per channel a
+// stage is FREE, FIXED (dw = target - w: on its box, or a fixed number of rate steps before a
+// stage that is) or TIED (dw = dw of the previous stage + what restores the rate constraint).
+// With u_n the non-free part of the policy (sigma v + o) the stage policy is
+//   u = u_n - Hi (Hux dx + Huv v + Huu u_n + hu),   Hi = inverse of Huu on the free controls,
+// i.e. u = -(Lx dx + Lv v + k) with Lx = Hi Hux, Lv = Hi (Huv + Huu Sigma) - Sigma,
+// k = Hi (hu + Huu o) - o, and the value function follows from the general affine policy:
+//   P' = Hzz - L' Huz - M' L,  p' = hz - L' hu - M' k,  M = Huz - Huu L   (z = (dx, v)).
+// Right-hand side: minus the stored gradient.  Stores the gains and the feed-forward.
+__device__ __forceinline__ void rounds_riccati(const Store &s, const Problem &p, const Sets &S, const uint64_t (&fixedR)[2],
+                                               bool run)
+{
+    const int T = s.T;
+    Riccati R;
+    R.terminal(p.qf);
+    double qg = 1.0;
+    for (int t = 1; t < T; ++t) qg *= p.growth;
+    double tau[2] = {0.0, 0.0};
+    double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
+    _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
+        Dyn d;
+        load_dyn(s, t, d);
+        double wp[2] = {0.0, 0.0};
+        if (t > 0) { wp[0] = s.ld(s.p(s.fW, t - 1, 0)); wp[1] = s.ld(s.p(s.fW, t - 1, 1)); }
+        double sig[2], o[2], wr[2], we[2], wq[3], gr[2];
+        bool fr[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bool fx = bit(fixedR[c], t);
+            const bool up_prev = t > 0 && bit(S.ru[c], t - 1), dn_prev = t > 0 && bit(S.rl[c], t - 1);
+            sig[c] = 0.0; o[c] = 0.0;
+            fr[c] = false;
+            if (fx) {
+                double target;
+                if (bit(S.bu[c], t)) target = p.hi(t, c);
+                else if (bit(S.bl[c], t)) target = p.lo(t, c);
+                else target = tau[c] - (bit(S.ru[c], t) ? p.fb.rr[c] : -p.fb.rr[c]);
+                tau[c] = target;
+                o[c] = target - wc[c];
+            } else if (up_prev || dn_prev) {
+                sig[c] = 1.0;
+                o[c] = (up_prev ? p.fb.rr[c] : -p.fb.rr[c]) - (wc[c] - wp[c]);
+            } else {
+                fr[c] = true;
+            }
+            wr[c] = 2.0 * p.rw[c];
+            we[c] = t > 0 ? 2.0 * p.rdw[c] : 0.0;
+            gr[c] = s.ld(s.p(s.fGr, t, c));
+            wc[c] = wp[c];
+        }
+        stage_weight(p, t, qg, wq);
+        // Q-function blocks
+        double BP[2][3];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                BP[c][j] = fma(d.b[0][c], R.Pxx(0, j), fma(d.b[1][c], R.Pxx(1, j), fma(d.b[2][c], R.Pxx(2, j), R.xu[j][c])));
+        double h00 = wr[0] + we[0] + R.uu[0], h01 = R.uu[1], h11 = wr[1] + we[1] + R.uu[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            h00 = fma(BP[0][j], d.b[j][0], fma(d.b[j][0], R.xu[j][0], h00));
+            h01 = fma(BP[0][j], d.b[j][1], fma(d.b[j][0], R.xu[j][1], h01));
+            h11 = fma(BP[1][j], d.b[j][1], fma(d.b[j][1], R.xu[j][1], h11));
+        }
+        const double Huu[2][2] = {{h00, h01}, {h01, h11}};
+        double Hux[2][3];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            Hux[c][0] = BP[c][0];
+            Hux[c][1] = BP[c][1];
+            Hux[c][2] = fma(d.a02, BP[c][0], fma(d.a12, BP[c][1], BP[c][2]));
+        }
+        double hu[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            hu[c] = fma(d.b[0][c], R.px[0], fma(d.b[1][c], R.px[1], fma(d.b[2][c], R.px[2], R.pu[c]))) + gr[c];
+        // inverse on the free controls
+        double i00 = 0.0, i01 = 0.0, i11 = 0.0;
+        if (fr[0] && fr[1]) {
+            const double idet = rcp_nr(fma(h00, h11, -h01 * h01));
+            i00 = h11 * idet; i01 = -h01 * idet; i11 = h00 * idet;
+        } else if (fr[0]) {
+            i00 = rcp_nr(h00);
+        } else if (fr[1]) {
+            i11 = rcp_nr(h11);
+        }
+        // G = Huv + Huu Sigma (2 x 2), hv = hu + Huu o
+        double G[2][2], ho[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) G[r][e] = (r == e ? -we[e] : 0.0) + Huu[r][e] * sig[e];
+            ho[r] = hu[r] + Huu[r][0] * o[0] + Huu[r][1] * o[1];
+        }
+        double Lx[2][3], Lv[2][2], k[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            Lx[0][j] = fma(i00, Hux[0][j], i01 * Hux[1][j]);
+            Lx[1][j] = fma(i01, Hux[0][j], i11 * Hux[1][j]);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            Lv[0][e] = fma(i00, G[0][e], i01 * G[1][e]) - (e == 0 ? sig[0] : 0.0);
+            Lv[1][e] = fma(i01, G[0][e], i11 * G[1][e]) - (e == 1 ? sig[1] : 0.0);
+        }
+        k[0] = fma(i00, ho[0], i01 * ho[1]) - o[0];
+        k[1] = fma(i01, ho[0], i11 * ho[1]) - o[1];
+        if (run) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) s.st(s.f(s.fLx + c * 3 + j, t), Lx[c][j]);
+                s.st(s.f(s.fLv + c * 2, t), Lv[c][0]);
+                s.st(s.f(s.fLv + c * 2 + 1, t), Lv[c][1]);
+                s.st(s.p(s.fKv, t, c), k[c]);
+            }
+        }
+        if (t > 0) {
+            // M = Huz - Huu L
+            double Mx[2][3], Mv[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) Mx[r][j] = Hux[r][j] - fma(Huu[r][0], Lx[0][j], Huu[r][1] * Lx[1][j]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) Mv[r][e] = (r == e ? -we[e] : 0.0) - fma(Huu[r][0], Lv[0][e], Huu[r][1] * Lv[1][e]);
+            }
+            // A' Pxx A
+            const double m00 = R.xx[0], m01 = R.xx[1], m02 = R.xx[2], m11 = R.xx[3], m12 = R.xx[4], m22 = R.xx[5];
+            const double n02 = fma(d.a02, m00, fma(d.a12, m01, m02));
+            const double n12 = fma(d.a02, m01, fma(d.a12, m11, m12));
+            const double n22 = fma(d.a02, m02 + n02, fma(d.a12, m12 + n12, m22));
+            const double Hxx[6] = {wq[0] + m00, m01, n02, wq[1] + m11, n12, wq[2] + n22};
+            Riccati N;
+            int e6 = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = i; j < 3; ++j, ++e6)
+                    N.xx[e6] = Hxx[e6] - fma(Lx[0][i], Hux[0][j], Lx[1][i] * Hux[1][j]) - fma(Mx[0][i], Lx[0][j], Mx[1][i] * Lx[1][j]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)   // Huv is diagonal: (Lx' Huv)[i][e] = -Lx[e][i] we[e]
+                    N.xu[i][e] = Lx[e][i] * we[e] - fma(Mx[0][i], Lv[0][e], Mx[1][i] * Lv[1][e]);
+            // Pvv' = We - Lv' Huv - Mv' Lv
+            N.uu[0] = we[0] + Lv[0][0] * we[0] - fma(Mv[0][0], Lv[0][0], Mv[1][0] * Lv[1][0]);
+            N.uu[1] = Lv[1][0] * we[1] - fma(Mv[0][0], Lv[0][1], Mv[1][0] * Lv[1][1]);
+            N.uu[2] = we[1] + Lv[1][1] * we[1] - fma(Mv[0][1], Lv[0][1], Mv[1][1] * Lv[1][1]);
+            const double p2 = fma(d.a02, R.px[0], fma(d.a12, R.px[1], R.px[2]));
+            const double hx[3] = {R.px[0], R.px[1], p2};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                N.px[i] = hx[i] - fma(Lx[0][i], hu[0], Lx[1][i] * hu[1]) - fma(Mx[0][i], k[0], Mx[1][i] * k[1]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                N.pu[e] = -fma(Lv[0][e], hu[0], Lv[1][e] * hu[1]) - fma(Mv[0][e], k[0], Mv[1][e] * k[1]);
+            R = N;
+        }
+        qg = qg / p.growth;
+    }
+}
+
+// Forward sweep of a round: the step of the working-set problem, the new controls (a control on
+// its box lands on it exactly), the rollout for the next adjoint, and every constraint the new
+// point violates (`add`).  A working set with more constraints than controls on a stretch (a box
+// at both ends of a chain of rate constraints) cannot hold everywhere unless its values happen
+// to fit: members the new point does not sit on are returned in `loose`.
+__device__ __forceinline__ void rounds_forward(const Store &s, const Problem &p, const Sets &S, bool run, Sets &add,
+                                               Sets &loose, double &check)
+{
+    double wpn[2] = {0.0, 0.0};   // new controls of the previous stage
+    Roller ro;
+    ro.start(p);
+    forward(s, [&](int t, const double (&u)[2]) {
+        double wst[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            double wnew = s.ld(s.p(s.fW, t, c)) + u[c];
+            if (bit(S.bu[c], t)) wnew = p.hi(t, c);
+            else if (bit(S.bl[c], t)) wnew = p.lo(t, c);
+            wst[c] = wnew;
+            check += wnew;
+            if (p.hb(t, c)) {
+                if (wnew - p.hi(t, c) > kFeasTol) add.bu[c] |= one(t);
+                if (p.lo(t, c) - wnew > kFeasTol) add.bl[c] |= one(t);
+            }
+            if (t > 0 && p.hr(c)) {
+                const double dv = wnew - wpn[c];
+                if (dv - p.fb.rr[c] > kFeasTol) add.ru[c] |= one(t - 1);
+                if (-dv - p.fb.rr[c] > kFeasTol) add.rl[c] |= one(t - 1);
+                if (bit(S.ru[c], t - 1) && p.fb.rr[c] - dv > kFeasTol) loose.ru[c] |= one(t - 1);
+                if (bit(S.rl[c], t - 1) && p.fb.rr[c] + dv > kFeasTol) loose.rl[c] |= one(t - 1);
+            }
+            if (run) s.st(s.p(s.fW, t, c), wnew);
+            wpn[c] = wnew;
+        }
+        ro.step(s, p, t, wst[0], wst[1]);   // for the next round's adjoint sweep
+    });
+}
+
+// Starts from the interior-point iterate on the lanes with `run`; returns true where a point is
+// certified (then w holds it), otherwise w is put back as it was (the interior point's
+// multipliers are never touched, so it can go on from there).
+__device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_rounds, bool run, int &used)
+{
+    used = 0;
+    const int T = s.T;
     const bool ran = run;
-    // initial set: multiplier above slack; the same sweep rolls the dynamics for the first round
+    Sets S;
+    S.clear();
+    // working set off the iterate (multiplier above slack), backup of the controls, rollout
     if (__any(run)) {
         Roller ro;
         ro.start(p);
@@ -703,146 +1065,71 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
             for (int c = 0; c < 2; ++c) {
                 const double wc = s.ld(s.p(s.fW, t, c));
                 wst[c] = wc;
-                if (!run) continue;
-                s.st(s.p(s.fBak, t, c), wc);
-                const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
-                const bool au = p.hb(t, c) && lu > p.hi(t, c) - wc, al = p.hb(t, c) && ll > wc - p.lo(t, c);
-                s.st(s.p(s.fLU, t, c), au ? lu : 0.0);
-                s.st(s.p(s.fLL, t, c), al ? ll : 0.0);
-                s.st(s.p(s.fSetB, t, c), (double)((au ? 1 : 0) | (al ? 2 : 0)));
-                if (t > 0) {
+                if (run) s.st(s.p(s.fBak, t, c), wc);
+                if (p.hb(t, c)) {
+                    const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
+                    if (lu > p.hi(t, c) - wc) S.bu[c] |= one(t);
+                    else if (ll > wc - p.lo(t, c)) S.bl[c] |= one(t);
+                }
+                if (t > 0 && p.hr(c)) {
                     const double dv = wc - wpv[c];
                     const double nu = s.ld(s.p(s.fNU, t - 1, c)), nl = s.ld(s.p(s.fNL, t - 1, c));
-                    const bool bu = p.hr(c) && nu > p.fb.rr[c] - dv, bl = p.hr(c) && nl > p.fb.rr[c] + dv;
-                    s.st(s.p(s.fNU, t - 1, c), bu ? nu : 0.0);
-                    s.st(s.p(s.fNL, t - 1, c), bl ? nl : 0.0);
-                    s.st(s.p(s.fSetR, t - 1, c), (double)((bu ? 1 : 0) | (bl ? 2 : 0)));
+                    if (nu > p.fb.rr[c] - dv) S.ru[c] |= one(t - 1);
+                    else if (nl > p.fb.rr[c] + dv) S.rl[c] |= one(t - 1);
                 }
                 wpv[c] = wc;
             }
             ro.step(s, p, t, wst[0], wst[1]);
         }
     }
-    bool changed = true, accepted = false;
+    bool accepted = false;
+    bool violated = true;   // no point of this working set has been checked yet
     for (int round = 0;; ++round) {
         if (!__any(run)) break;
-        double stat = 0.0, scl = 0.0, viol = 0.0, cact = 0.0, neg = 0.0, fsum = 0.0;
-        {
-            Riccati R;
-            R.terminal(p.qf);
-            double lam[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0;
-            double wn[2] = {0.0, 0.0}, dnun[2] = {0.0, 0.0}, trn[2] = {0.0, 0.0};
-            double qg = 1.0;
-            for (int t = 1; t < T; ++t) qg *= p.growth;
-            double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
-            _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
-                Dyn d;
-                load_dyn(s, t, d);
-                adjoint_step(s, t, a02n, a12n, lam);
-                double wr[2], we[2], wq[3], r[2];
+        if (run) used = round;
+        uint64_t fixedR[2];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    double wp = 0.0, nup = 0.0, nlp = 0.0;
-                    int setp = 0;
-                    if (t > 0) {
-                        wp = s.ld(s.p(s.fW, t - 1, c));
-                        nup = s.ld(s.p(s.fNU, t - 1, c));
-                        nlp = s.ld(s.p(s.fNL, t - 1, c));
-                        setp = (int)s.ld(s.p(s.fSetR, t - 1, c));
-                    }
-                    const int setc = (int)s.ld(s.p(s.fSetB, t, c));
-                    const bool au = setc & 1, al = setc & 2, bu = setp & 1, bl = setp & 2;
-                    const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
-                    const double dv = wc[c] - wp;
-                    const double vu = wc[c] - p.hi(t, c), vl = p.lo(t, c) - wc[c];
-                    const double ru = dv - p.fb.rr[c], rl = -dv - p.fb.rr[c];
-                    const double cu = au ? vu : 0.0, cl = al ? vl : 0.0, du = bu ? ru : 0.0, dl = bl ? rl : 0.0;
-                    const double hw = input_cost_grad(p, c, t, T, wp, wc[c], wn[c])
-                                      + fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
-                    const double gl = hw + (lu - ll) + (nup - nlp) - dnun[c];
-                    const double ga = rho * ((cu - cl) + (du - dl) - trn[c]);
-                    if (p.hb(t, c)) viol = dmax(viol, dmax(vu, vl));
-                    if (p.hr(c) && t > 0) viol = dmax(viol, dmax(ru, rl));
-                    cact = dmax(cact, dmax(dmax(fabs(cu), fabs(cl)), dmax(fabs(du), fabs(dl))));
-                    neg = dmax(neg, dmax(dmax(-lu, -ll), dmax(-nup, -nlp)));
-                    stat = dmax(stat, fabs(gl));
-                    const double g = s.ld(s.p(s.fG, t, c));
-                    scl = dmax(scl, dmax(fabs(g), fabs(hw - g)));
-                    fsum += gl + ga + wc[c];
-                    wr[c] = 2.0 * p.rw[c] + rho * ((au ? 1.0 : 0.0) + (al ? 1.0 : 0.0));
-                    we[c] = t > 0 ? 2.0 * p.rdw[c] + rho * ((bu ? 1.0 : 0.0) + (bl ? 1.0 : 0.0)) : 0.0;
-                    r[c] = -(gl + ga);
-                    dnun[c] = nup - nlp;
-                    trn[c] = du - dl;
-                    wn[c] = wc[c];
-                    wc[c] = wp;
-                }
-                stage_weight(p, t, qg, wq);
-                Gains gn;
-                riccati_matrix_step(s, t, d, wr, we, wq, R, gn, run);
-                riccati_vector_step(s, t, d, r, gn.Lx, gn.Lv, gn.Hi, R, run);
-                a02n = d.a02; a12n = d.a12;
-                qg = qg / p.growth;
+        for (int c = 0; c < 2; ++c) fixedR[c] = fixed_from_right(S.bu[c] | S.bl[c], S.ru[c] | S.rl[c], T);
+        Sets drop;
+        drop.clear();
+        double check = 0.0;
+        rounds_adjoint(s, p, S, fixedR, drop);
+        const bool stat_ok = rounds_multipliers(s, S, fixedR, drop, check);
+        bool dropped = false;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) dropped = dropped || (drop.bu[c] | drop.bl[c] | drop.ru[c] | drop.rl[c]) != 0;
+        const bool fin = finite_d(check);
+        // the first pass looks at the interior-point iterate, which is not on its working set:
+        // nothing is dropped or accepted on it
+        if (round > 0) {
+            if (run && fin && stat_ok && !violated && !dropped) { accepted = true; run = false; }
+            if (run && (round >= max_rounds || !fin)) run = false;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                S.bu[c] &= ~drop.bu[c]; S.bl[c] &= ~drop.bl[c];
+                S.ru[c] &= ~drop.ru[c]; S.rl[c] &= ~drop.rl[c];
             }
-        }
-        const double scale = dmax(1.0, scl) + 1.0;
-        const bool fin = finite_d(fsum);   // max() drops NaN operands
-        if (run && !changed && fin && stat <= 1e-10 * scale && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) {
-            accepted = true;
+        } else if (run && !fin) {
             run = false;
         }
-        if (run && (round >= max_rounds || !fin)) run = false;
         if (!__any(run)) break;
-        // forward: Newton step of the augmented Lagrangian, multiplier update, set correction
-        // (box of stage t, and the rate constraint (t - 1, t) once both its controls are new)
-        const double ntol = -1e-9 * scale;
-        bool ch = false;
-        {
-            double wpn[2] = {0.0, 0.0};   // new controls of the previous stage
-            Roller ro;
-            ro.start(p);
-            forward(s, [&](int t, const double (&u)[2]) {
-                double wst[2];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const double wnew = s.ld(s.p(s.fW, t, c)) + u[c];
-                    wst[c] = wnew;
-                    const int setc = (int)s.ld(s.p(s.fSetB, t, c));
-                    const bool au = setc & 1, al = setc & 2;
-                    const double vu2 = wnew - p.hi(t, c), vl2 = p.lo(t, c) - wnew;
-                    const double lu = au ? fma(rho, vu2, s.ld(s.p(s.fLU, t, c))) : 0.0;
-                    const double ll = al ? fma(rho, vl2, s.ld(s.p(s.fLL, t, c))) : 0.0;
-                    const bool au2 = p.hb(t, c) && ((au && lu >= ntol) || vu2 > 1e-12);
-                    const bool al2 = p.hb(t, c) && ((al && ll >= ntol) || vl2 > 1e-12);
-                    ch = ch || au2 != au || al2 != al;
-                    if (run) {
-                        s.st(s.p(s.fW, t, c), wnew);
-                        s.st(s.p(s.fLU, t, c), au2 ? dmax(lu, 0.0) : 0.0);
-                        s.st(s.p(s.fLL, t, c), al2 ? dmax(ll, 0.0) : 0.0);
-                        s.st(s.p(s.fSetB, t, c), (double)((au2 ? 1 : 0) | (al2 ? 2 : 0)));
-                    }
-                    if (t > 0) {
-                        const int setp = (int)s.ld(s.p(s.fSetR, t - 1, c));
-                        const bool bu = setp & 1, bl = setp & 2;
-                        const double dv2 = wnew - wpn[c];
-                        const double ru2 = dv2 - p.fb.rr[c], rl2 = -dv2 - p.fb.rr[c];
-                        const double nu = bu ? fma(rho, ru2, s.ld(s.p(s.fNU, t - 1, c))) : 0.0;
-                        const double nl = bl ? fma(rho, rl2, s.ld(s.p(s.fNL, t - 1, c))) : 0.0;
-                        const bool bu2 = p.hr(c) && ((bu && nu >= ntol) || ru2 > 1e-12);
-                        const bool bl2 = p.hr(c) && ((bl && nl >= ntol) || rl2 > 1e-12);
-                        ch = ch || bu2 != bu || bl2 != bl;
-                        if (run) {
-                            s.st(s.p(s.fNU, t - 1, c), bu2 ? dmax(nu, 0.0) : 0.0);
-                            s.st(s.p(s.fNL, t - 1, c), bl2 ? dmax(nl, 0.0) : 0.0);
-                            s.st(s.p(s.fSetR, t - 1, c), (double)((bu2 ? 1 : 0) | (bl2 ? 2 : 0)));
-                        }
-                    }
-                    wpn[c] = wnew;
-                }
-                ro.step(s, p, t, wst[0], wst[1]);   // for the next round's adjoint sweep
-            });
+        for (int c = 0; c < 2; ++c) fixedR[c] = fixed_from_right(S.bu[c] | S.bl[c], S.ru[c] | S.rl[c], T);
+        rounds_riccati(s, p, S, fixedR, run);
+        Sets add, loose;
+        add.clear();
+        loose.clear();
+        double chk2 = 0.0;
+        rounds_forward(s, p, S, run, add, loose, chk2);
+        if (run && !finite_d(chk2)) run = false;
+        violated = false;   // "the working set changed after the point was computed"
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            violated = violated || (add.bu[c] | add.bl[c] | add.ru[c] | add.rl[c] | loose.ru[c] | loose.rl[c]) != 0;
+            S.bu[c] = (S.bu[c] | add.bu[c]) & ~add.bl[c]; S.bl[c] = (S.bl[c] | add.bl[c]) & ~add.bu[c];
+            S.ru[c] = ((S.ru[c] & ~loose.ru[c]) | add.ru[c]) & ~add.rl[c];
+            S.rl[c] = ((S.rl[c] & ~loose.rl[c]) | add.rl[c]) & ~add.ru[c];
         }
-        changed = ch;
     }
     if (ran && !accepted)
         for (int t = 0; t < T; ++t) {

