@@ -5,54 +5,85 @@ ackermann equalities) instances per GPU.
 A "step" is one iterative_linear_mpc_control pass over the whole batch (rollout + T
 linearisations + one QP per instance) with every input already resident in HBM.
 One process per GPU; instances are independent, so ranks share nothing and the only
-collective is the max-over-ranks of the elapsed time ("weak" scaling: 65,536 per rank).
+collectives are the barrier and the max-over-ranks of the elapsed time.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 8                      # starts 8 ranks itself (one GPU each)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --scaling strong --workload mixed4m
+        # 4,194,304 instances, a quarter each diff-drive / dual-steer ackermann / crab / fixed
+        # steer (T = 5), sorted by variant and split evenly over the N GPUs; reports the solve
+        # rate and, separately, the time of the per-GPU gather of the results into pinned host memory
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from model_predictive_control_amd import engine, sharding, variants, workload  # noqa: E402
-
 VARIANT = "dsr_ackermann"
 BATCH = 65536
+MIXED_VARIANTS = ("diff_drive", "dsr_ackermann", "dsr_crab", "dsr_diff")
+MIXED_TOTAL = 4194304
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
 SOLVE_KERNEL = "k_solve_pair5<dual-steer, single QP>"   # two lanes per instance, T=5, everything on chip
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+SQ_FILE = os.path.join(ROOT, "profiles", "pair5_sq_counters.json")
+WARM_TICKS = 9     # closed-loop ticks run before the timed solve: the timed pass is tick 10
 
 
-def measured_traffic():
-    """HBM bytes per launch of the solve kernel from rocprofv3 counter passes of this same
-    command (FETCH_SIZE doubled as gfx950 tallies 128-B requests at 64 B, plus WRITE_SIZE);
-    written by scripts/summarise_pmc.py. None when no counter pass has been recorded."""
+def ranks_to_spawn(gpus: int, env) -> int:
+    """How many rank processes this invocation has to start itself: `--gpus N` with N > 1 and no
+    launcher around it (no WORLD_SIZE in the environment); 0 otherwise."""
+    if gpus > 1 and "WORLD_SIZE" not in env:
+        return gpus
+    return 0
+
+
+def kernel_source_hash() -> str:
+    """Identifies the kernels a recorded profile belongs to: sha256 over csrc/ and the header."""
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "model_predictive_control_amd", "csrc")
+    for f in sorted(os.listdir(base)) + [os.path.join(ROOT, "include", "mpcx.h")]:
+        with open(f if os.path.isabs(f) else os.path.join(base, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_counters(batch: int):
+    """Counter results recorded under profiles/ by separate rocprofv3 --pmc passes of this same
+    command (scripts/gpu_validate.sh): HBM bytes per launch of the solve kernel (FETCH_SIZE
+    doubled as gfx950 tallies 128-B requests at 64 B, plus WRITE_SIZE) and the fraction of wave
+    cycles that issue a VALU instruction.  They are replays of files, not measurements of this
+    run, and are dropped when the kernels have changed since they were recorded."""
+    out = {"traffic": None, "valu_busy_frac": None, "from_profiles": None}
+    now = kernel_source_hash()
+    src = {}
     try:
         with open(TRAFFIC_FILE) as f:
             rec = json.load(f)
-        return float(rec["bytes_per_launch"]) if rec.get("batch") == BATCH else None
+        if rec.get("batch") == batch and rec.get("csrc_sha") == now:
+            out["traffic"] = float(rec["bytes_per_launch"])
+            src["traffic"] = {"file": os.path.relpath(TRAFFIC_FILE, ROOT), "csrc_sha": rec["csrc_sha"]}
     except (OSError, ValueError, KeyError):
-        return None
-
-
-def measured_valu_busy():
-    """Fraction of the solve kernel's wave cycles that issue a VALU instruction, from the SQ
-    counter passes recorded in profiles/ (scripts/pmc_pair.sh); None if not recorded."""
+        pass
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pair5_sq_counters.json")) as f:
-            return float(json.load(f)["valu_busy_frac"])
+        with open(SQ_FILE) as f:
+            rec = json.load(f)
+        if rec.get("batch") == batch and rec.get("csrc_sha") == now:
+            out["valu_busy_frac"] = float(rec["valu_busy_frac"])
+            src["valu_busy_frac"] = {"file": os.path.relpath(SQ_FILE, ROOT), "csrc_sha": rec["csrc_sha"]}
     except (OSError, ValueError, KeyError):
-        return None
+        pass
+    if src:
+        out["from_profiles"] = src
+    return out
 
 
 def algorithmic_bytes(nu: int, T: int) -> int:
@@ -61,13 +92,12 @@ def algorithmic_bytes(nu: int, T: int) -> int:
     return 16 * nu * T + 48 * (T + 1) + 41
 
 
-WARM_TICKS = 9     # closed-loop ticks run before the timed solve: the timed pass is tick 10
-
-
 def build_inputs(rank: int, B: int):
     """Synthetic vehicles on synthetic spline courses, driven for WARM_TICKS closed-loop ticks
     on the GPU; returns the inputs of the next tick's solve (device tensors): state, reference
     window, previous optimum (fed back unshifted, as the reference's loop does) and its flag."""
+    import torch
+    from model_predictive_control_amd import engine, sharding, variants, workload
     v = variants.get(VARIANT)
     courses = workload.make_courses(1024, seed=1001)
     inst = workload.make_instances(courses, B, seed=sharding.rank_seed(2002, rank))
@@ -82,7 +112,8 @@ def build_inputs(rank: int, B: int):
 def cpu_baseline(x0, xref, uprev, has_prev, seconds_target: float = 12.0):
     """The C restatement of the same path (oracle/mpc_oracle.c, polish off) timed on the
     host cores of this box over repeated passes of the benchmark's own batch, about
-    `seconds_target` seconds of CPU work in all."""
+    `seconds_target` seconds of CPU work in all; plus, only where cvxpy is importable, the
+    reference's own formulation (cvxpy + ECOS, rebuilt per call as the reference does) on one core."""
     from oracle import mpc_oracle as O
     from oracle import orc
     ov = O.variant(VARIANT)
@@ -109,11 +140,8 @@ def cpu_baseline(x0, xref, uprev, has_prev, seconds_target: float = 12.0):
         if dt1 >= seconds_target * 0.25:
             break
     orc.set_polish(True)
-    try:
-        import cvxpy  # noqa: F401
-        cvx = "importable (not timed: the reference's files are not on this box)"
-    except Exception:
-        cvx = "cvxpy baseline unavailable offline"
+    from tools import cvxpy_baseline
+    cvx = cvxpy_baseline.run(VARIANT, x0, xref, uprev, has_prev, n_solves=200)
     return {"value": done / dt, "unit": "solves/s", "cores": threads, "kind": "port",
             "sample": f"{done} solves = {done // n} passes over the benchmark's own {n} instances, C float64 "
                       f"interior-point port of the same path, {threads} OpenMP threads, {dt:.1f} s",
@@ -122,12 +150,17 @@ def cpu_baseline(x0, xref, uprev, has_prev, seconds_target: float = 12.0):
 
 def other_configs(steps: int = 3):
     """The survey's other single-GPU configurations, timed briefly beside the headline one
-    (warm-started from their own cold optimum, inputs resident): 262,144 diff-drive T=5,
-    65,536 mpc.py T=10, 65,536 dual-steer T=30."""
+    (inputs resident; "warm" = linearised at their own cold optimum, as the reference's loop
+    feeds the previous answer back): 262,144 diff-drive T=5, 65,536 mpc.py T=10, and mpc_dsr.py
+    at T=30 both ways: the QP its iterative_linear_mpc_control actually calls (fixed steer, stage
+    weights Q 2^t, mpc_dsr.py:193,349) and the ackermann one."""
+    import torch
+    from model_predictive_control_amd import engine, variants, workload
     res = []
     courses = workload.make_courses(64, seed=1001)
     for name, B, T, kernel in (("diff_drive", 262144, None, "k_solve_pair5<diff-drive>"),
                                ("mpc_py", 65536, None, "k_solve_pair10<dual-steer>"),
+                               ("dsr_diff", 65536, 30, "k_solve_stage<dual-steer>"),
                                ("dsr_ackermann", 65536, 30, "k_solve_stage<dual-steer>")):
         v = variants.get(name, T=T) if T else variants.get(name)
         inst = workload.make_instances(courses, B, seed=2003)
@@ -136,29 +169,78 @@ def other_configs(steps: int = 3):
         d_x0 = torch.from_numpy(inst["state"][:, :3].copy()).cuda()
         out = engine.solve_batch(v, d_x0, d_xref)
         up = out["u"].clone()
-        engine.solve_batch(v, d_x0, d_xref, up, out=out)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            engine.solve_batch(v, d_x0, d_xref, up, out=out)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
         ab = algorithmic_bytes(v.nu, v.T)
-        res.append({"workload": f"{name} T={v.T} batch {B}", "value": B / dt, "unit": "solves/s", "ms_per_step": dt * 1e3,
-                    "kernel": kernel, "solved_fraction": float((out["status"] <= 1).float().mean().item()),
-                    "algorithmic_GBps": ab * B / dt / 1e9})
+        for start, u in (("cold", None), ("warm", up)):
+            if start == "cold" and T != 30:
+                continue
+            engine.solve_batch(v, d_x0, d_xref, u, out=out)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                engine.solve_batch(v, d_x0, d_xref, u, out=out)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            res.append({"workload": f"{name} T={v.T} batch {B} {start}", "value": B / dt, "unit": "solves/s",
+                        "ms_per_step": dt * 1e3, "kernel": kernel,
+                        "solved_fraction": float((out["status"] <= 1).float().mean().item()),
+                        "failed": int((out["status"] == 4).sum().item()),
+                        "algorithmic_GBps": ab * B / dt / 1e9})
     return res
+
+
+def mixed_inputs(rank: int, world: int, total: int):
+    """This rank's part of the variant-sorted mixed batch: [(variant struct, x0, xref, uprev)] per
+    variant piece, device tensors, warm-started from the piece's own cold optimum."""
+    import numpy as np
+    import torch
+    from model_predictive_control_amd import engine, sharding, variants, workload
+    counts = [total // len(MIXED_VARIANTS)] * len(MIXED_VARIANTS)
+    counts[-1] += total - sum(counts)
+    courses = workload.make_courses(1024, seed=1001)
+    table = engine.CourseTable(courses)
+    parts = []
+    for k, lo, hi in sharding.variant_segments(counts, rank, world):
+        v = variants.get(MIXED_VARIANTS[k])
+        inst = workload.make_instances(courses, counts[k], seed=3003 + k)      # the whole block, then this rank's rows
+        sl = slice(lo, hi)
+        state = np.ascontiguousarray(inst["state"][sl])
+        _, _, xref = engine.nearest_ref_batch(1, v.T, v.dt, 2, state, inst["course_id"][sl], inst["pind"][sl], table)
+        x0 = torch.from_numpy(np.ascontiguousarray(state[:, :3])).cuda()
+        out = engine.solve_batch(v, x0, xref)
+        parts.append(dict(name=MIXED_VARIANTS[k], v=v, x0=x0, xref=xref, uprev=out["u"].clone(), out=out, n=hi - lo))
+    torch.cuda.synchronize()
+    return parts
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--workload", choices=("headline", "mixed4m"), default=None)
+    ap.add_argument("--total", type=int, default=MIXED_TOTAL, help="instances of the mixed workload (all ranks together)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
+    workload_name = args.workload or ("mixed4m" if args.scaling == "strong" else "headline")
+    if workload_name == "mixed4m":
+        args.scaling = "strong"
+    if args.steps is None:
+        args.steps = 50 if workload_name == "headline" else 10
+    if args.warmup is None:
+        args.warmup = 5 if workload_name == "headline" else 2
+
+    # `--gpus N` without a launcher: start the N ranks here, before anything touches the GPU
+    n_spawn = ranks_to_spawn(args.gpus, os.environ)
+    if n_spawn:
+        from model_predictive_control_amd import sharding
+        sys.exit(sharding.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], n_spawn))
+
+    import numpy as np
+    import torch
+    from model_predictive_control_amd import engine, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -177,13 +259,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend)
-
-    B = args.batch
-    v, d_x0, d_xref, d_uprev, d_has = build_inputs(rank, B)
-    out = engine.solve_batch(v, d_x0, d_xref, d_uprev, d_has)
-    torch.cuda.synchronize()
-    ok = int((out["status"] <= 1).sum().item())
-    warm_fraction = float(d_has.float().mean().item())
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
         torch.cuda.synchronize()
@@ -191,59 +267,115 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if workload_name == "headline":
+        B = args.batch
+        v, d_x0, d_xref, d_uprev, d_has = build_inputs(rank, B)
+        out = engine.solve_batch(v, d_x0, d_xref, d_uprev, d_has)
+        torch.cuda.synchronize()
+        ok = int((out["status"] <= 1).sum().item())
+        warm_fraction = float(d_has.float().mean().item())
+
+        def step():
+            engine.solve_batch(v, d_x0, d_xref, d_uprev, d_has, out=out)
+        units_here, bytes_here = B, algorithmic_bytes(v.nu, v.T) * B
+    else:
+        parts = mixed_inputs(rank, world, args.total)
+
+        def step():
+            for p in parts:
+                engine.solve_batch(p["v"], p["x0"], p["xref"], p["uprev"], out=p["out"])
+        step()
+        torch.cuda.synchronize()
+        ok = sum(int((p["out"]["status"] <= 1).sum().item()) for p in parts)
+        units_here = sum(p["n"] for p in parts)
+        bytes_here = sum(algorithmic_bytes(p["v"].nu, p["v"].T) * p["n"] for p in parts)
+
     for _ in range(args.warmup):
-        engine.solve_batch(v, d_x0, d_xref, d_uprev, d_has, out=out)
+        step()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k].record()                                 # same stream the kernel is launched on
-        engine.solve_batch(v, d_x0, d_xref, d_uprev, d_has, out=out)
+        ev[k].record()                                 # same stream the kernels are launched on
+        step()
     ev[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dist, "cuda")
-    ok = int(sharding.sum_over_ranks(ok, dist, "cuda"))
-    per_launch_ms = np.array([ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)])
+    elapsed = sharding.max_over_ranks(elapsed, dist, red_dev)
+    ok = int(sharding.sum_over_ranks(ok, dist, red_dev))
+    units_all = int(sharding.sum_over_ranks(units_here, dist, red_dev))
+    per_step_ms = np.array([ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)])
+
+    gather_ms = None
+    if workload_name == "mixed4m":
+        # the final result gather: each GPU copies its outputs into pinned host memory (no
+        # GPU-to-GPU traffic); timed on its own, never part of the solve rate
+        host = [{k: torch.empty(t.shape, dtype=t.dtype).pin_memory() for k, t in p["out"].items()} for p in parts]
+        barrier()
+        tg = time.perf_counter()
+        for p, h in zip(parts, host):
+            for k, t in p["out"].items():
+                h[k].copy_(t, non_blocking=True)
+        torch.cuda.synchronize()
+        gather_ms = sharding.max_over_ranks((time.perf_counter() - tg) * 1e3, dist, red_dev)
+        gathered_bytes = sharding.sum_over_ranks(sum(t.numel() * t.element_size() for h in host for t in h.values()), dist, red_dev)
 
     if rank == 0:
-        kernel_s = float(per_launch_ms.mean()) * 1e-3
-        bytes_per_launch = algorithmic_bytes(v.nu, v.T) * B
-        achieved = bytes_per_launch / kernel_s / 1e9
+        kernel_s = float(per_step_ms.mean()) * 1e-3
+        achieved = bytes_here / kernel_s / 1e9
         line = {
             "metric": "MPC solves/sec (T=5 bicycle, batch 64k)",
-            "value": sharding.whole_job_rate(B, world, args.steps, elapsed),
+            "value": units_all * args.steps / elapsed,
             "unit": "solves/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{B} independent T=5 general-bicycle (dual-steer NX=3 NU=4, ackermann "
-                                   "equalities, mpc_dsr.py:201-267) instances per GPU on 1024 synthetic cubic-spline "
-                                   f"courses; the timed solve is tick {WARM_TICKS + 1} of a closed-loop run (previous optimum "
-                                   "fed back unshifted)", "variant": VARIANT, "batch_per_gpu": B,
-                       "horizon": v.T, "parallelism": f"independent shards x{world}, no collective"},
-            "p50_batch_latency_ms": float(np.median(per_launch_ms)),
-            "solved_fraction": ok / (B * world), "warm_fraction_rank0": warm_fraction,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic() if B == BATCH else None,
-                         "kernel": SOLVE_KERNEL, "kernel_ms": kernel_s * 1e3,
-                         "kernel_ms_note": "HIP events on the launch stream, back-to-back launches: includes the ~4 us "
-                                           "dispatch gap between consecutive kernels that a kernel trace leaves out",
-                         "algorithmic_bytes_per_solve": algorithmic_bytes(v.nu, v.T),
-                         "valu_busy_frac": measured_valu_busy() if B == BATCH else None,
-                         "note": "the solve is FP64-VALU issue bound (5 interior-point iterations + ~4 active-set "
-                                 "rounds, one 10x10 Cholesky each, per instance); HBM fraction reported as the task asks"},
+            "solved_fraction": ok / units_all,
         }
-        if not args.no_other_configs and world == 1:
+        if workload_name == "headline":
+            line["config"] = {"workload": f"{B} independent T=5 general-bicycle (dual-steer NX=3 NU=4, ackermann "
+                                          "equalities, mpc_dsr.py:201-267) instances per GPU on 1024 synthetic cubic-spline "
+                                          f"courses; the timed solve is tick {WARM_TICKS + 1} of a closed-loop run (previous "
+                                          "optimum fed back unshifted)", "variant": VARIANT, "batch_per_gpu": B,
+                              "horizon": v.T, "parallelism": f"independent shards x{world}, no collective"}
+            line["p50_batch_latency_ms"] = float(np.median(per_step_ms))
+            line["warm_fraction_rank0"] = warm_fraction
+            rec = recorded_counters(B)
+            line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": achieved / HBM_PEAK_GBS, "traffic": rec["traffic"],
+                                "kernel": SOLVE_KERNEL, "kernel_ms": kernel_s * 1e3,
+                                "kernel_ms_note": "HIP events on the launch stream, back-to-back launches: includes the ~4 us "
+                                                  "dispatch gap between consecutive kernels that a kernel trace leaves out",
+                                "algorithmic_bytes_per_solve": algorithmic_bytes(v.nu, v.T),
+                                "valu_busy_frac": rec["valu_busy_frac"],
+                                "from_profiles": rec["from_profiles"],
+                                "from_profiles_note": "traffic and valu_busy_frac are replayed from counter passes recorded "
+                                                      "under profiles/ (not measured by this run) and are null when the "
+                                                      "kernel sources have changed since",
+                                "note": "the solve is FP64-VALU issue bound (5 interior-point iterations + ~4 active-set "
+                                        "rounds, one 10x10 Cholesky each, per instance); HBM fraction reported as the task asks"}
+        else:
+            line["metric"] = "MPC solves/sec (T=5 mixed-model sweep, 4M instances)"
+            line["config"] = {"workload": f"{units_all} instances, a quarter each of {', '.join(MIXED_VARIANTS)} (T=5), sorted "
+                                          "by variant so every wavefront is homogeneous, contiguous ranges per GPU; "
+                                          "warm-started from their own cold optimum", "total": units_all,
+                              "parallelism": f"variant-sorted batch split x{world}, no collective"}
+            line["gather"] = {"ms": gather_ms, "bytes": gathered_bytes,
+                              "how": "per-GPU copy of u, x, obj, status, iters into pinned host memory, all ranks at "
+                                     "once, slowest rank's time; not part of value"}
+            line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                "kernel": "k_solve_pair5 (four instantiations, one launch per variant piece)",
+                                "kernel_ms": kernel_s * 1e3, "note": "rank 0's algorithmic bytes per step / its step time"}
+        if not args.no_other_configs and world == 1 and workload_name == "headline":
             line["other_configs"] = other_configs()
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and workload_name == "headline":
             line["cpu_baseline"] = cpu_baseline(d_x0.cpu().numpy(), d_xref.cpu().numpy(), d_uprev.cpu().numpy(),
                                                 d_has.cpu().numpy())
         print(json.dumps(line), flush=True)

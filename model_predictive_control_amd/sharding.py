@@ -78,6 +78,51 @@ def gather_rows(local: np.ndarray, total: int, dist=None) -> np.ndarray | None:
     return out
 
 
+def variant_segments(counts: Sequence[int], rank: int, world: int) -> List[Tuple[int, int, int]]:
+    """A batch of several variants laid out variant after variant (so that every wavefront is
+    homogeneous), counts[k] instances of variant k, is split into `world` contiguous ranges; this
+    rank's range as (variant, start, stop) pieces with start/stop inside that variant's block."""
+    total = int(sum(counts))
+    lo, hi = partition(total, world)[rank]
+    out, base = [], 0
+    for k, n in enumerate(counts):
+        a, b = max(lo, base), min(hi, base + n)
+        if a < b:
+            out.append((k, a - base, b - base))
+        base += n
+    return out
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(cmd: Sequence[str], world: int, env=None, timeout=None) -> int:
+    """Starts `world` fresh processes of `cmd`, one rank each (RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_ADDR = 127.0.0.1 and a free MASTER_PORT in their environment, the way
+    torch.distributed.run does), waits for all and returns the largest exit code.  The caller must
+    not have touched the GPU: the children are new programs, nothing is inherited or replaced."""
+    import os
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(world):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(list(cmd), env=e))
+    rc = 0
+    for pr in procs:
+        try:
+            rc = max(rc, abs(pr.wait(timeout=timeout)))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            rc = max(rc, 124)
+    return rc
+
+
 def whole_job_rate(units_per_rank: int, world: int, steps: int, elapsed_max: float) -> float:
     """Aggregate units/s over all ranks for `steps` passes timed at the slowest rank."""
     return world * units_per_rank * steps / elapsed_max

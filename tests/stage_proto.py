@@ -1,4 +1,4 @@
-"""Numpy prototype of the stage-wise active-set rounds with exact elimination (test/dev tool).
+"""Numpy restatement of the stage-wise active-set rounds with exact elimination (test infrastructure).
 
 Per channel and stage a control is FREE, FIXED (box active, or tied forward to a fixed one) or
 TIED (rate constraint to the previous stage active: it moves with the previous control).  The

@@ -76,3 +76,41 @@ def test_two_ranks_split_solve_gather(tmp_path):
     world, total = 2, 37     # odd on purpose: ragged split 19 + 18
     mp.spawn(_worker, args=(world, _free_port(), total, str(tmp_path)), nprocs=world, join=True)
     assert (tmp_path / "ok").exists()
+
+
+def test_variant_segments_cover_a_variant_sorted_batch():
+    counts = [1048576] * 4
+    for world in (1, 2, 3, 4, 8):
+        seen = [0] * 4
+        for r in range(world):
+            segs = sharding.variant_segments(counts, r, world)
+            assert 1 <= len(segs) <= 2 or world == 1
+            for k, a, b in segs:
+                assert 0 <= a < b <= counts[k]
+                seen[k] += b - a
+        assert seen == counts
+    assert sharding.variant_segments([5, 0, 7], 1, 2) == [(2, 1, 7)]
+
+
+def test_bench_launcher_spawns_the_ranks_it_is_asked_for(tmp_path):
+    """`bench.py --gpus N` without a launcher around it must start N ranks itself: the spawner
+    gives each child its rank, the world size and a common rendezvous address."""
+    code = ("import os, sys; open(os.path.join(sys.argv[1], 'r' + os.environ['RANK']), 'w').write("
+            "os.environ['WORLD_SIZE'] + ' ' + os.environ['LOCAL_RANK'] + ' ' + os.environ['MASTER_ADDR'] + ' ' + os.environ['MASTER_PORT'])")
+    rc = sharding.spawn_ranks([sys.executable, "-c", code, str(tmp_path)], 3)
+    assert rc == 0
+    got = [open(tmp_path / f"r{r}").read().split() for r in range(3)]
+    assert [g[0] for g in got] == ["3"] * 3 and [g[1] for g in got] == ["0", "1", "2"]
+    assert len({g[3] for g in got}) == 1 and got[0][2] == "127.0.0.1"
+    assert sharding.spawn_ranks([sys.executable, "-c", "import sys; sys.exit(3)"], 2) == 3
+
+
+def test_bench_py_decides_to_spawn_before_touching_the_gpu():
+    """bench.py's launcher decision is pure argument/environment logic (no torch.cuda call)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.ranks_to_spawn(8, {}) == 8
+    assert bench.ranks_to_spawn(1, {}) == 0
+    assert bench.ranks_to_spawn(8, {"WORLD_SIZE": "8", "RANK": "3"}) == 0     # already under a launcher
