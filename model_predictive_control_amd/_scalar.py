@@ -51,12 +51,30 @@ def linearize_one(v, theta, ucol):
     return A.cpu().numpy()[0], B.cpu().numpy()[0], C.cpu().numpy()[0]
 
 
+_TABLES = {}      # content fingerprint of (cx, cy, cyaw) -> device CourseTable, most recent last
+_TABLES_MAX = 8
+
+
+def course_table(cx, cy, cyaw):
+    """Device table of one course given as lists, cached by content: the reference's callers pass
+    the same lists tick after tick (and smooth or pop them in place in between, which a cache
+    keyed by identity would miss), so a tick costs a hash of the lists instead of an upload."""
+    ax, ay, aw = (np.ascontiguousarray(a, dtype=np.float64) for a in (cx, cy, cyaw))
+    key = (ax.size, hash(ax.tobytes()), hash(ay.tobytes()), hash(aw.tobytes()))
+    table = _TABLES.pop(key, None)
+    if table is None:
+        table = engine.CourseTable([(ax, ay, aw)])
+        while len(_TABLES) >= _TABLES_MAX:
+            _TABLES.pop(next(iter(_TABLES)))
+    _TABLES[key] = table
+    return table
+
+
 def nearest_ref_one(mode, T, dt, param, state, cx, cy, cyaw, pind, n_search, sign=True):
     """calc_nearest_index + reference window for one state on one course given as lists.
     Raises ValueError on the empty search window like min([]) does in the reference
     (mpc_diff_drive.py:110)."""
-    table = engine.CourseTable([(np.asarray(cx, dtype=np.float64), np.asarray(cy, dtype=np.float64),
-                                 np.asarray(cyaw, dtype=np.float64))])
+    table = course_table(cx, cy, cyaw)
     st = np.asarray([[float(state.x), float(state.y), float(getattr(state, "yaw", 0.0)),
                       float(getattr(state, "vx", 0.0))]])
     ind, mind, xref = engine.nearest_ref_batch(mode, T, dt, param, st, None, np.asarray([int(pind)], dtype=np.int32),
@@ -65,3 +83,43 @@ def nearest_ref_one(mode, T, dt, param, state, cx, cy, cyaw, pind, n_search, sig
     if ind < 0:
         raise ValueError("min() arg is an empty sequence")
     return ind, float(mind.cpu()[0]), xref.cpu().numpy()[0]
+
+
+def closed_loop_one(v, cx, cy, cyaw, state, goal_dis, stop_speed, dt, max_time, max_ticks=None, n_search=10,
+                    chunk=64):
+    """do_simulation for one vehicle on the device-resident loop (engine.ClosedLoop with B = 1):
+    initial yaw compensation, first nearest index from the course start, then per tick reference
+    window -> solve -> update_state -> check_goal with no host round trip; the host looks at the
+    `done` flag once per `chunk` ticks.  Returns per-tick lists t, x, y, yaw, vx, vy, w (first
+    entry = the initial state) and updates `state` to the final one.  Raises ValueError where the
+    reference does (empty search window)."""
+    table = course_table(cx, cy, cyaw)
+    # ticks the reference's `while max_time >= time` loop can take (time accumulates in floating point)
+    limit, tm = 0, 0.0
+    while max_time >= tm and (max_ticks is None or limit < max_ticks):
+        tm += dt
+        limit += 1
+    st0 = np.asarray([[float(state.x), float(state.y), float(state.yaw), float(getattr(state, "vx", 0.0))]])
+    loop = engine.ClosedLoop(v, table, st0, None, goal_dis=goal_dis, stop_speed=stop_speed, n_search=n_search,
+                             log_ticks=limit, log_twist=True)
+    if int(loop.target_ind.cpu()[0]) < 0:
+        raise ValueError("min() arg is an empty sequence")
+    done = 0
+    while loop.n_done_ticks < limit and not done:
+        loop.run(min(chunk, limit - loop.n_done_ticks))
+        done = int(loop.done.cpu()[0])
+    n = int(loop.ticks.cpu()[0])
+    if done == 2:
+        raise ValueError("min() arg is an empty sequence")
+    log = loop.log[:n + 1, 0].cpu().numpy()
+    tw = loop.twist_log[:n + 1, 0].cpu().numpy()
+    t = [0.0]
+    for _ in range(n):
+        t.append(t[-1] + dt)
+    state.x, state.y, state.yaw, state.vx = (float(a) for a in log[n])
+    if hasattr(state, "vy"):
+        state.vy = float(tw[n, 0])
+    if hasattr(state, "w"):
+        state.w = float(tw[n, 1])
+    return dict(t=t, x=log[:, 0].tolist(), y=log[:, 1].tolist(), yaw=log[:, 2].tolist(), vx=log[:, 3].tolist(),
+                vy=tw[:, 0].tolist(), w=tw[:, 1].tolist(), goal=done == 1, target_ind=int(loop.target_ind.cpu()[0]))

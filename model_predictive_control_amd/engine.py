@@ -236,7 +236,7 @@ class ClosedLoop:
 
     def __init__(self, v: CVariant, table: CourseTable, state, course_id=None, goal_dis: float = 1.5,
                  stop_speed: float = 0.5 / 3.6, n_search_ind: int = 2, n_search: int = 10, log_ticks: int = 0,
-                 pind0=None):
+                 pind0=None, log_twist: bool = False):
         self.lib = _lib.load()
         self.v, self.table = v, table
         self.state = _dev(state).clone()
@@ -260,6 +260,8 @@ class ClosedLoop:
         self.out = _outputs(B, v.nu, v.T, dev)
         self.uprev = torch.zeros((B, v.nu, v.T), dtype=torch.float64, device=dev)
         self.log = torch.empty((log_ticks + 1, B, 4), dtype=torch.float64, device=dev) if log_ticks else None
+        # (vy, w) applied per tick, kept beside the state log when asked for (row 0: at rest)
+        self.twist_log = torch.zeros((log_ticks + 1, B, 2), dtype=torch.float64, device=dev) if log_ticks and log_twist else None
         self.n_done_ticks = 0
         self._initial_alignment()
 
@@ -303,6 +305,8 @@ class ClosedLoop:
                                           _ptr(t.cx), _ptr(t.cy), _ptr(t.clen), t.K, t.Lmax, _ptr(self.state),
                                           _ptr(self.twist), _ptr(self.has_prev), _ptr(self.done), _ptr(self.ticks),
                                           _ptr(log), st))
+        if self.twist_log is not None and k < self.twist_log.shape[0]:
+            self.twist_log[k].copy_(self.twist)
         o["u"], self.uprev = self.uprev, o["u"]   # this optimum warm-starts the next tick
         self.n_done_ticks = k
 
@@ -345,6 +349,128 @@ class ClosedLoop:
     @property
     def last_u(self):
         return self.uprev
+
+
+class SegmentedLoop:
+    """Device-resident closed loop over courses that change motion mode along the way
+    (MPC.doSimulationWithAllMotionModes, mpc_sim.py:254-265, over the segments
+    splitTrajectoryWithMotionModes cuts, :674-690): every vehicle drives its list of segments one
+    after the other, each segment a course of its own (a row of `table`) in its own mode, exactly
+    as the reference runs one doSimulation per segment: cold start, initial yaw compensation and
+    first nearest index from the segment's start, until the goal test of that segment passes or
+    `max_ticks_per_segment` ticks are spent; then the next segment starts from the state reached.
+
+    variants[m]: the solver variant of mode m (same model, horizon and dt for all);
+    seg_mode [K]: mode index of every table row;  seg_start [B], seg_count [B]: each vehicle's rows
+    (consecutive).  Per tick the solves are launched per mode on the vehicles currently in it."""
+
+    def __init__(self, variants, table: CourseTable, seg_mode, seg_start, seg_count, state, max_ticks_per_segment: int,
+                 goal_dis: float = 1.5, stop_speed: float = 0.2, n_search_ind: int = 2, n_search: int = 10,
+                 log_ticks: int = 0):
+        self.lib = _lib.load()
+        self.variants, self.table = list(variants), table
+        v0 = self.variants[0]
+        if any(v.T != v0.T or v.nu != v0.nu or v.dt != v0.dt or v.model != v0.model for v in self.variants):
+            raise ValueError("the modes of a segmented loop must share model, horizon and dt")
+        self.state = _dev(state).clone()
+        B = self.B = self.state.shape[0]
+        dev = self.state.device
+        self.seg_mode = _dev(seg_mode, torch.int64)
+        self.seg_start = _dev(seg_start, torch.int64)
+        self.seg_count = _dev(seg_count, torch.int64)
+        self.cap = int(max_ticks_per_segment)
+        self.goal_dis, self.stop_speed = float(goal_dis), float(stop_speed)
+        self.n_search_ind, self.n_search = int(n_search_ind), int(n_search)
+        self.seg = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.seg_ticks = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.finished = self.seg_count <= 0
+        self.course_id = (self.seg_start + self.seg).to(torch.int32)
+        self.twist = torch.zeros((B, 2), dtype=torch.float64, device=dev)
+        self.has_prev = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self.done = self.finished.to(torch.uint8)
+        self.ticks = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.target_ind = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.xref = torch.empty((B, 3, v0.T + 1), dtype=torch.float64, device=dev)
+        self.x0 = torch.empty((B, 3), dtype=torch.float64, device=dev)
+        self.out = _outputs(B, v0.nu, v0.T, dev)
+        self.out["status"].fill_(_lib.ST_FAILED)
+        self.uprev = torch.zeros((B, v0.nu, v0.T), dtype=torch.float64, device=dev)
+        self.log = torch.empty((log_ticks + 1, B, 4), dtype=torch.float64, device=dev) if log_ticks else None
+        self.n_done_ticks = 0
+        self._enter_segment(torch.nonzero(~self.finished).flatten())
+        if self.log is not None:
+            self.log[0].copy_(self.state)
+
+    def _enter_segment(self, idx):
+        """What doSimulation does before its loop (mpc_sim.py:204-222) for the vehicles `idx`
+        entering their current segment: yaw compensation against the segment's first yaw, first
+        nearest index searched from the segment's start, cold start."""
+        if idx.numel() == 0:
+            return
+        t = self.table
+        cid = self.course_id[idx].long()
+        yaw = self.state[idx, 2]
+        d = yaw - t.cyaw[cid, 0]
+        two_pi = 2.0 * math.pi
+        self.state[idx, 2] = torch.where(d >= math.pi, yaw - two_pi, torch.where(d <= -math.pi, yaw + two_pi, yaw))
+        st = self.state[idx].contiguous()
+        ind, _, _ = nearest_ref_batch(1, self.variants[0].T, self.variants[0].dt, float(self.n_search_ind), st,
+                                      self.course_id[idx].contiguous(), torch.zeros(idx.numel(), dtype=torch.int32, device=st.device),
+                                      t, n_search=self.n_search, want_xref=False)
+        self.target_ind[idx] = ind
+        self.has_prev[idx] = 0
+        self.done[idx] = 0
+        self.seg_ticks[idx] = 0
+
+    def tick(self):
+        t, v0, lib, st = self.table, self.variants[0], self.lib, _stream()
+        _lib.check(lib.mpcx_nearest_ref_batch(1, v0.T, v0.dt, float(self.n_search_ind), self.n_search, 1, self.B,
+                                              _ptr(self.state), _ptr(self.course_id), _ptr(self.target_ind),
+                                              _ptr(t.cx), _ptr(t.cy), _ptr(t.cyaw), _ptr(t.clen), t.K, t.Lmax,
+                                              _ptr(self.target_ind), None, _ptr(self.xref), st))
+        self.x0.copy_(self.state[:, :3])
+        o = self.out
+        mode = self.seg_mode[self.course_id.long().clamp(0, t.K - 1)]
+        active = ~self.finished & (self.done == 0)
+        for m, v in enumerate(self.variants):
+            idx = torch.nonzero(active & (mode == m)).flatten()
+            if idx.numel() == 0:
+                continue
+            part = solve_batch(v, self.x0[idx], self.xref[idx], self.uprev[idx], self.has_prev[idx])
+            o["u"][idx] = part["u"]
+            o["status"][idx] = part["status"]
+        k = self.n_done_ticks + 1
+        log = self.log[k] if self.log is not None and k < self.log.shape[0] else None
+        _lib.check(lib.mpcx_advance_batch(C.byref(v0), self.B, self.goal_dis, self.stop_speed, _ptr(o["u"]),
+                                          _ptr(o["status"]), _ptr(self.target_ind), _ptr(self.course_id),
+                                          _ptr(t.cx), _ptr(t.cy), _ptr(t.clen), t.K, t.Lmax, _ptr(self.state),
+                                          _ptr(self.twist), _ptr(self.has_prev), _ptr(self.done), _ptr(self.ticks),
+                                          _ptr(log), st))
+        o["u"], self.uprev = self.uprev, o["u"]
+        self.n_done_ticks = k
+        # segment bookkeeping: goal reached or the segment's ticks spent -> next segment; a lost
+        # reference window (where the reference raises) ends the vehicle's run
+        self.seg_ticks += active.long()
+        lost = active & (self.done == 2)
+        move = active & ~lost & ((self.done == 1) | (self.seg_ticks >= self.cap))
+        self.finished |= lost
+        if bool(move.any().item()):
+            self.seg += move.long()
+            ended = move & (self.seg >= self.seg_count)
+            self.finished |= ended
+            go = move & ~ended
+            self.course_id = torch.where(go, (self.seg_start + self.seg).to(torch.int32), self.course_id)
+            self.done = torch.where(ended, torch.ones_like(self.done), self.done)
+            self._enter_segment(torch.nonzero(go).flatten())
+        if self.log is not None and k < self.log.shape[0]:
+            self.log[k].copy_(self.state)     # after a possible yaw compensation of the next segment
+
+    def run(self, n_ticks: int):
+        for _ in range(n_ticks):
+            if bool(self.finished.all().item()):
+                break
+            self.tick()
+        return self
 
 
 class HostPipeline:

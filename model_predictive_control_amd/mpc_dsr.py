@@ -157,34 +157,16 @@ def check_goal(state, goal, tind, nind):
 
 
 def do_simulation(cx, cy, cyaw, dl, initial_state, max_ticks=None):
-    """Closed loop of mpc_dsr.py:504-589 without the plotting."""
-    goal = [cx[-1], cy[-1]]
+    """Closed loop of mpc_dsr.py:504-589 without the plotting, run on the device-resident loop
+    (the fixed-steer QP iterative_linear_mpc_control calls, mpc_dsr.py:193); `cyaw` is smoothed in
+    place and `initial_state` ends as the final state, as in the reference."""
     state = initial_state
-    if state.yaw - cyaw[0] >= math.pi:
-        state.yaw -= math.pi * 2.0
-    elif state.yaw - cyaw[0] <= -math.pi:
-        state.yaw += math.pi * 2.0
-    time = 0.0
-    x, y, yaw, vx, vy, w, t = [state.x], [state.y], [state.yaw], [state.vx], [state.vy], [state.w], [0.0]
-    target_ind, _ = calc_nearest_index(state, cx, cy, cyaw, 0)
-    ovf, ovr, osf, osr = None, None, None, None
     cyaw = smooth_yaw(cyaw)
-    ticks = 0
-    while MAX_TIME >= time and (max_ticks is None or ticks < max_ticks):
-        xref, target_ind = calc_ref_trajectory2(state, cx, cy, cyaw, 2, target_ind)
-        x0 = [state.x, state.y, state.yaw]
-        ovf, ovr, osf, osr, ox, oy, oyaw = iterative_linear_mpc_control(xref, x0, ovf, ovr, osf, osr)
-        if ovf is not None:
-            vxi, vyi, wi = transfrom_gbm_command(ovf[0], ovr[0], osf[0], osr[0])
-            state = update_state(state, vxi, vyi, wi)
-        time = time + DT
-        ticks += 1
-        x.append(state.x); y.append(state.y); yaw.append(state.yaw)
-        vx.append(state.vx); vy.append(state.vy); w.append(state.w); t.append(time)
-        if check_goal(state, goal, target_ind, len(cx)):
-            print("Goal")
-            break
-    return t, x, y, yaw, vx, w
+    r = _scalar.closed_loop_one(_variant(LMPC_MODE), cx, cy, cyaw, state, GOAL_DIS, STOP_SPEED, DT, MAX_TIME,
+                                max_ticks=max_ticks, n_search=N_IND_SEARCH)
+    if r["goal"]:
+        print("Goal")
+    return r["t"], r["x"], r["y"], r["yaw"], r["vx"], r["w"]
 
 
 def smooth_yaw(yaw):

@@ -62,6 +62,9 @@ class GeneralBicycleModel:
         return _scalar.linearize_one(v, theta, [v_f, delta_f, v_r, delta_r])
 
 
+MODES = ("ackermann", "diff", "crab")      # mode index of engine.SegmentedLoop
+
+
 class MPC:
     """mpc_sim.py:165-553"""
 
@@ -110,48 +113,42 @@ class MPC:
         return None
 
     def doSimulation(self, cx, cy, cyaw, initial_state, mode='ackermann', max_time=500, dt=0.2, max_ticks=None):
-        """Closed loop of mpc_sim.py:201-252 without the plotting."""
-        goal = [cx[-1], cy[-1]]
+        """Closed loop of mpc_sim.py:201-252 without the plotting, run on the device-resident loop
+        (per tick: reference window, the chained QPs of iterativeLMPC in one launch, updateState,
+        checkGoal; no host round trip).  `cyaw` is smoothed in place and `initial_state` ends as
+        the final state, as in the reference."""
         state = initial_state
-        if state.yaw - cyaw[0] >= math.pi:
-            state.yaw -= math.pi * 2.0
-        elif state.yaw - cyaw[0] <= -math.pi:
-            state.yaw += math.pi * 2.0
-        time = 0.0
-        x, y, yaw, vx, vy, w, t = [state.x], [state.y], [state.yaw], [state.vx], [state.vy], [state.w], [0.0]
-        target_ind, _ = self.getNearestIndex(state, cx, cy, cyaw, 0)
-        ovf, ovr, osf, osr = None, None, None, None
         cyaw = smooth_yaw(cyaw)
-        ticks = 0
-        while max_time >= time and (max_ticks is None or ticks < max_ticks):
-            x0 = [state.x, state.y, state.yaw]
-            xref, target_ind = self.getReferenceTrajectory(state, cx, cy, cyaw, 2, target_ind)
-            ovf, ovr, osf, osr, ox, oy, oyaw = self.iterativeLMPC(xref, x0, ovf, ovr, osf, osr, mode)
-            if ovf is not None:
-                vxi, vyi, wi = self.gbm_.transformWheelCommandToRobotCommand(ovf[0], ovr[0], osf[0], osr[0])
-                state = self.gbm_.updateState(state, vxi, vyi, wi)
-            time = time + dt
-            ticks += 1
-            x.append(state.x); y.append(state.y); yaw.append(state.yaw)
-            vx.append(state.vx); vy.append(state.vy); w.append(state.w); t.append(time)
-            if self.checkGoal(state, goal, target_ind, len(cx)):
-                print("Goal Reached.")
-                break
-        return t, x, y, yaw, vx, vy, w, state
+        v = self._variant(mode, chain=self.horizon_)     # `dt` only advances the clock (mpc_sim.py:235); model and QP keep 0.2
+        if v is None:                       # unknown mode: the reference's iterativeLMPC returns None and raises
+            raise TypeError("cannot unpack non-iterable NoneType object")
+        r = _scalar.closed_loop_one(v, cx, cy, cyaw, state, self.xy_tolerance_, self.stop_speed_, dt, max_time,
+                                    max_ticks=max_ticks, n_search=10)
+        if r["goal"]:
+            print("Goal Reached.")
+        return r["t"], r["x"], r["y"], r["yaw"], r["vx"], r["vy"], r["w"], state
 
-    def doSimulationWithAllMotionModes(self, idx_group, cx, cy, cyaw, cmode, initial_state, max_time=500, dt=0.2):
-        """mpc_sim.py:254-265: one closed loop per course segment, each in its own mode.
-        (The reference returns nothing; the per-segment results are returned here.)"""
+    def doSimulationWithAllMotionModes(self, idx_group, cx, cy, cyaw, cmode, initial_state, max_time=500, dt=0.2,
+                                       max_ticks=None):
+        """mpc_sim.py:254-265: one closed loop per course segment, each in its own mode and each
+        on the device-resident loop.  (The reference returns nothing; the per-segment results are
+        returned here.  Like the reference, the segments run with doSimulation's default max_time
+        and dt; `max_ticks` bounds every segment.)  A fleet of vehicles on such courses runs as
+        one batch through engine.SegmentedLoop."""
         current_state = initial_state
         results = []
         for idx in idx_group:
-            lx = cx[idx[0]: idx[1] + 1]
-            ly = cy[idx[0]: idx[1] + 1]
-            lyaw = cyaw[idx[0]: idx[1] + 1]
-            res = self.doSimulation(lx, ly, lyaw, current_state, cmode[idx[0]], max_time, dt)
+            lx = list(cx[idx[0]: idx[1] + 1])
+            ly = list(cy[idx[0]: idx[1] + 1])
+            lyaw = list(cyaw[idx[0]: idx[1] + 1])
+            res = self.doSimulation(lx, ly, lyaw, current_state, cmode[idx[0]], max_ticks=max_ticks)
             results.append(res)
             current_state = res[-1]
         return results
+
+    def segment_variants(self):
+        """The three modes' solver variants in the order engine.SegmentedLoop indexes them."""
+        return [self._variant(m, chain=self.horizon_) for m in MODES]
 
     def predictMotion(self, x0, vf, vr, sf, sr, xref):
         T = self.horizon_
@@ -264,10 +261,10 @@ def main4(file_name='reference_diff.csv', max_ticks=None):
     return _run_recorded(file_name, 2, 'diff', max_ticks)
 
 
-def main5(file_name='output.csv'):
+def main5(file_name='output.csv', max_ticks=None):
     """Recorded trajectory with a motion mode per node: one simulation per mode segment."""
     tg = TrajectoryGenerator()
     cx, cy, cyaw, cmode = tg.interpolateReference2(tg.retriveTrajectoryFromCSV(file_name), 3)
     idx_group = tg.splitTrajectoryWithMotionModes(cmode)
     initial_state = State(x=cx[0], y=cy[0], yaw=cyaw[0])
-    return MPC().doSimulationWithAllMotionModes(idx_group, cx, cy, cyaw, cmode, initial_state)
+    return MPC().doSimulationWithAllMotionModes(idx_group, cx, cy, cyaw, cmode, initial_state, max_ticks=max_ticks)

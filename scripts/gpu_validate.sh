@@ -1,19 +1,36 @@
 #!/bin/bash
-# Round validation on the GPU box: GPU tests, smoke, bench, kernel-trace stats and the two
-# HBM counter passes of the same bench command.  Every GPU step has its own time limit and the
-# chain stops at the first failure.
+# Round validation on the GPU box: GPU tests, smoke, bench, kernel-trace stats, and the counter
+# passes (each in a run of its own) of the headline kernel, the T = 10 kernel and the stage-wise
+# kernel.  Every GPU step has its own time limit and the chain stops at the first failure.
+# Afterwards, here: python scripts/summarise_profiles.py <tag>  (writes profiles/).
 set -o pipefail
-TAG=${1:-r1}
+TAG=${1:-r2}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 120 --timeout-method thread > $OUT/gputests.log 2>&1 \
+pmc() {  # pmc <dir> <counters...> -- <script args...>
+  local d=$1; shift; local ctr=(); while [ "$1" != "--" ]; do ctr+=("$1"); shift; done; shift
+  timeout -s KILL 150 rocprofv3 --pmc "${ctr[@]}" --output-format csv -d $OUT/$d -o p -- python3 "$@" > $OUT/$d.log 2>&1
+}
+SQ_A="SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES"
+SQ_B="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_LDS"
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 300 --timeout-method thread > $OUT/gputests.log 2>&1 \
  && tail -3 $OUT/gputests.log \
  && timeout -k 10 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1 \
  && tail -1 $OUT/smoke.log \
  && timeout -k 10 300 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err \
- && cat $OUT/bench.json \
+ && timeout -k 10 300 python bench.py --workload mixed4m > $OUT/mixed4m.json 2> $OUT/mixed4m.err \
  && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1 \
- && timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_fetch.log 2>&1 \
- && timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_write.log 2>&1 \
+ && pmc pmc_fetch FETCH_SIZE -- bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs \
+ && pmc pmc_write WRITE_SIZE -- bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs \
+ && pmc sq5_a $SQ_A -- scripts/prof_solve.py dsr_ackermann 65536 5 \
+ && pmc sq5_b $SQ_B -- scripts/prof_solve.py dsr_ackermann 65536 5 \
+ && pmc p10_fetch FETCH_SIZE -- scripts/prof_solve.py mpc_py 65536 5 \
+ && pmc p10_write WRITE_SIZE -- scripts/prof_solve.py mpc_py 65536 5 \
+ && pmc p10_sq $SQ_A -- scripts/prof_solve.py mpc_py 65536 3 \
+ && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_trace -o p -- python3 scripts/prof_solve.py dsr_ackermann 65536 5 30 > $OUT/st_trace.log 2>&1 \
+ && pmc st_fetch FETCH_SIZE -- scripts/prof_solve.py dsr_ackermann 65536 5 30 \
+ && pmc st_write WRITE_SIZE -- scripts/prof_solve.py dsr_ackermann 65536 5 30 \
+ && pmc st_sq SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INSTS_SALU -- scripts/prof_solve.py dsr_ackermann 65536 3 30 \
+ && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sd_trace -o p -- python3 scripts/prof_solve.py dsr_diff 65536 5 30 > $OUT/sd_trace.log 2>&1 \
  && echo validate-done

@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Summaries of a scripts/gpu_validate.sh run (gpurun_out/<tag>/) into profiles/: kernel-trace
+stats, HBM traffic per launch (FETCH_SIZE x2 on gfx950: 128-byte requests are tallied at 64
+bytes; both counters in units of 1024 bytes) and SQ counters per wave, each stamped with the
+hash of the kernel sources it was recorded with.   usage: summarise_profiles.py <tag> [round]"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r2"
+OUT = os.path.join(ROOT, "gpurun_out", tag)
+PROF = os.path.join(ROOT, "profiles")
+sha = bench.kernel_source_hash()
+
+
+def find(sub, name):
+    hits = glob.glob(os.path.join(OUT, sub, "**", name), recursive=True)
+    return hits[0] if hits else None
+
+
+def per_dispatch(path, kernel, counter=None):
+    """{counter: median over dispatches of the sum over the dispatch's rows}, and waves per dispatch."""
+    acc = collections.defaultdict(float)
+    grid = None
+    for r in csv.DictReader(open(path)):
+        if kernel in r["Kernel_Name"] and (counter is None or r["Counter_Name"] == counter):
+            acc[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+            grid = int(r["Grid_Size"]) // 64
+    per = collections.defaultdict(list)
+    for (d, c), v in acc.items():
+        per[c].append(v)
+    return {c: sorted(v)[len(v) // 2] for c, v in per.items()}, grid, {c: len(v) for c, v in per.items()}
+
+
+def kernel_stats(sub, prefix, dest):
+    p = find(sub, prefix + "_kernel_stats.csv")
+    if p:
+        shutil.copy(p, os.path.join(PROF, dest))
+        return {r["Name"]: r for r in csv.DictReader(open(p))}
+    return {}
+
+
+def traffic(fetch_sub, write_sub, kernel):
+    pf, pw = find(fetch_sub, "p_counter_collection.csv"), find(write_sub, "p_counter_collection.csv")
+    if not pf or not pw:
+        return None
+    f, _, nf = per_dispatch(pf, kernel, "FETCH_SIZE")
+    w, _, nw = per_dispatch(pw, kernel, "WRITE_SIZE")
+    return {"fetch_size_kb_raw": f["FETCH_SIZE"], "write_size_kb_raw": w["WRITE_SIZE"],
+            "fetch_bytes": 2.0 * f["FETCH_SIZE"] * 1024.0, "write_bytes": w["WRITE_SIZE"] * 1024.0,
+            "bytes_per_launch": 2.0 * f["FETCH_SIZE"] * 1024.0 + w["WRITE_SIZE"] * 1024.0,
+            "dispatches": [nf["FETCH_SIZE"], nw["WRITE_SIZE"]]}
+
+
+def sq(subs, kernel):
+    per_wave = {}
+    for sub in subs:
+        p = find(sub, "p_counter_collection.csv")
+        if not p:
+            continue
+        med, grid, _ = per_dispatch(p, kernel)
+        for c, v in med.items():
+            per_wave[c] = v / grid
+    return per_wave
+
+
+def avg_ns(stats, kernel):
+    for name, r in stats.items():
+        if kernel in name:
+            return float(r["AverageNs"]), int(r["Calls"])
+    return None, None
+
+
+how = "rocprofv3 --pmc, one counter group per run (scripts/gpu_validate.sh); median over dispatches"
+# headline kernel
+st = kernel_stats("trace", "t", f"{rnd}_bench_kernel_stats.csv")
+t = traffic("pmc_fetch", "pmc_write", "k_solve_pair5")
+if t:
+    t.update(kernel="k_solve_pair5", batch=65536, csrc_sha=sha, how=how + "; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B)")
+    ns, calls = avg_ns(st, "k_solve_pair5<1, false>")
+    t["kernel_trace_avg_ns"] = ns
+    json.dump(t, open(os.path.join(PROF, "hbm_traffic.json"), "w"), indent=1)
+    print("headline traffic", t["bytes_per_launch"], "avg ns", ns)
+pw = sq(["sq5_a", "sq5_b"], "k_solve_pair5")
+if pw:
+    rec = {"kernel": "k_solve_pair5<dual-steer, single QP>", "batch": 65536, "csrc_sha": sha, "per_wave": pw,
+           "valu_busy_frac": pw.get("SQ_ACTIVE_INST_VALU", 0.0) / pw["SQ_WAVE_CYCLES"] if pw.get("SQ_WAVE_CYCLES") else None,
+           "how": how + "; counters summed over the launch and divided by its waves; SQ_*_CYCLES and SQ_ACTIVE_* tick once per 4 clocks"}
+    json.dump(rec, open(os.path.join(PROF, "pair5_sq_counters.json"), "w"), indent=1)
+    print("headline valu busy", rec["valu_busy_frac"], "VALU/wave", pw.get("SQ_INSTS_VALU"))
+# T = 10 kernel
+t = traffic("p10_fetch", "p10_write", "k_solve_pair10")
+pw = sq(["p10_sq"], "k_solve_pair10")
+if t or pw:
+    rec = {"kernel": "k_solve_pair10<dual-steer>", "variant": "mpc_py", "T": 10, "batch": 65536, "csrc_sha": sha,
+           "algorithmic_bytes": 65536 * 1209, "traffic": t, "per_wave": pw, "how": how}
+    json.dump(rec, open(os.path.join(PROF, f"{rnd}_pair10_counters.json"), "w"), indent=1)
+    print("pair10 traffic", t and t["bytes_per_launch"], "algorithmic", 65536 * 1209)
+# stage-wise kernel, T = 30
+st = kernel_stats("st_trace", "p", f"{rnd}_stage_T30_kernel_stats.csv")
+kernel_stats("sd_trace", "p", f"{rnd}_stage_T30_dsr_diff_kernel_stats.csv")
+t = traffic("st_fetch", "st_write", "k_solve_stage")
+if t:
+    ns, calls = avg_ns(st, "k_solve_stage")
+    rec = {"kernel": "k_solve_stage<dual steer>", "variant": "dsr_ackermann", "T": 30, "batch": 65536, "csrc_sha": sha,
+           "avg_ns": ns, "launches": calls, "hbm_read_bytes": t["fetch_bytes"], "hbm_write_bytes": t["write_bytes"],
+           "hbm_GBps": (t["bytes_per_launch"]) / ns if ns else None, "algorithmic_bytes": 65536 * 3449, "how": how}
+    json.dump(rec, open(os.path.join(PROF, f"{rnd}_stage_T30_traffic.json"), "w"), indent=1)
+    print("stage T30", rec["avg_ns"], "ns", t["bytes_per_launch"] / 1e9, "GB per launch")
+pw = sq(["st_sq"], "k_solve_stage")
+if pw:
+    json.dump({"kernel": "k_solve_stage<dual steer>", "T": 30, "batch": 65536, "csrc_sha": sha, "per_wave": pw, "how": how},
+              open(os.path.join(PROF, f"{rnd}_stage_T30_sq_counters.json"), "w"), indent=1)
+for name in ("bench.json", "mixed4m.json"):
+    p = os.path.join(OUT, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(PROF, f"{rnd}_{name.replace('.json', '_line.json')}"))
