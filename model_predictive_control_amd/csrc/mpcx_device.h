@@ -43,7 +43,7 @@ constexpr double kLooseD = 1e-6;      // "inaccurate but accepted" thresholds
 constexpr double kLooseMu = 1e-7;
 constexpr double kEtaCap = 0.999;
 #ifndef MPCX_SWITCH_MU
-#define MPCX_SWITCH_MU 1e-5
+#define MPCX_SWITCH_MU 1e-6
 #endif
 constexpr double kSwitchMu = MPCX_SWITCH_MU;   // stage-wise kernel: complementarity at which the active set is read off the interior point
 constexpr double kSwitchD = 1e-3;     // ... and the relative dual residual it asks for

@@ -523,7 +523,7 @@ constexpr int kStageIpmCap = 40;   // interior-point iterations at most per atte
 constexpr int kStageAttempts = 3;
 // complementarity at which an attempt hands over to the active-set rounds (0: converged), and
 // the rounds it may take
-__device__ const double kStageSwitchMu[kStageAttempts] = {kSwitchMu, 1e-8, 0.0};
+__device__ const double kStageSwitchMu[kStageAttempts] = {kSwitchMu, 1e-9, 0.0};
 __device__ const int kStageRounds[kStageAttempts] = {MPCX_STAGE_R0, 6, 6};
 
 template <int MODEL>

@@ -155,6 +155,10 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
             int rounds = 0;
             const bool settled = MPCX_PAIR_NS::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1, &rounds);
             if (pass == 0 && attempt == 0 && threadIdx.x == 0 && blockIdx.x < kStampWaves) g_stamps[blockIdx.x * kStampSlots + 7] = rounds;
+#elif defined(MPCX_DIAG)   // diagnostic builds report the rounds in the iteration count
+            int rounds = 0;
+            const bool settled = MPCX_PAIR_NS::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1, &rounds);
+            if (need) iters += (attempt == 0 ? 100 : 10000) * (rounds + attempt) + (settled ? 0 : 1000000 * (attempt + 1));
 #else
             const bool settled = MPCX_PAIR_NS::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1);
 #endif

@@ -340,36 +340,6 @@ __device__ __forceinline__ double gradient_at_zero(const Store &s, const Problem
     return gmax;
 }
 
-// Diagonal entries (0, 0) and (1, 1) of the condensed H, the largest ones up to the input
-// weights: stage 0's controls act on every later state.  Scales the penalty of the rounds.
-__device__ __forceinline__ double hessian_scale(const Store &s, const Problem &p)
-{
-    const int T = s.T;
-    double G[2][3], h[2], qg = 1.0;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        h[c] = 2.0 * p.rw[c] + (T > 1 ? 2.0 * p.rdw[c] : 0.0);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) G[c][r] = s.dyn(2 + 2 * r + c, 0);
-    }
-    for (int ts = 1; ts <= T; ++ts) {
-        if (ts < T) qg *= p.growth;
-        if (ts > 1) {
-            const double a02 = s.dyn(0, ts - 1), a12 = s.dyn(1, ts - 1);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                G[c][0] = fma(a02, G[c][2], G[c][0]);
-                G[c][1] = fma(a12, G[c][2], G[c][1]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) h[c] = fma(2.0 * (ts < T ? p.q[r] * qg : p.qf[r]) * G[c][r], G[c][r], h[c]);
-    }
-    return dmax(h[0], h[1]);
-}
-
 // Stage weights going backward: Q growth^t for 0 < t < T (none at t = 0).
 __device__ __forceinline__ void stage_weight(const Problem &p, int t, double qg, double (&wq)[3])
 {
@@ -850,9 +820,12 @@ __device__ __forceinline__ bool rounds_multipliers(const Store &s, const Sets &S
 // i.e. u = -(Lx dx + Lv v + k) with Lx = Hi Hux, Lv = Hi (Huv + Huu Sigma) - Sigma,
 // k = Hi (hu + Huu o) - o, and the value function follows from the general affine policy:
 //   P' = Hzz - L' Huz - M' L,  p' = hz - L' hu - M' k,  M = Huz - Huu L   (z = (dx, v)).
-// Right-hand side: minus the stored gradient.  Stores the gains and the feed-forward.
+// Right-hand side: minus the gradient, either the one rounds_adjoint stored or (ADJOINT, the
+// first round, whose multipliers nobody looks at) formed on the way by the adjoint recursion.
+// Stores the gains and the feed-forward.
+template <bool ADJOINT>
 __device__ __forceinline__ void rounds_riccati(const Store &s, const Problem &p, const Sets &S, const uint64_t (&fixedR)[2],
-                                               bool run)
+                                               bool run, double &check)
 {
     const int T = s.T;
     Riccati R;
@@ -860,6 +833,7 @@ __device__ __forceinline__ void rounds_riccati(const Store &s, const Problem &p,
     double qg = 1.0;
     for (int t = 1; t < T; ++t) qg *= p.growth;
     double tau[2] = {0.0, 0.0};
+    double lam[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0, wn[2] = {0.0, 0.0};
     double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
     _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
         Dyn d;
@@ -868,6 +842,17 @@ __device__ __forceinline__ void rounds_riccati(const Store &s, const Problem &p,
         if (t > 0) { wp[0] = s.ld(s.p(s.fW, t - 1, 0)); wp[1] = s.ld(s.p(s.fW, t - 1, 1)); }
         double sig[2], o[2], wr[2], we[2], wq[3], gr[2];
         bool fr[2];
+        if (ADJOINT) {
+            adjoint_step(s, t, a02n, a12n, lam);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                gr[c] = input_cost_grad(p, c, t, T, wp[c], wc[c], wn[c])
+                        + fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
+                check += gr[c];
+                wn[c] = wc[c];
+            }
+            a02n = d.a02; a12n = d.a12;
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const bool fx = bit(fixedR[c], t);
@@ -889,7 +874,7 @@ __device__ __forceinline__ void rounds_riccati(const Store &s, const Problem &p,
             }
             wr[c] = 2.0 * p.rw[c];
             we[c] = t > 0 ? 2.0 * p.rdw[c] : 0.0;
-            gr[c] = s.ld(s.p(s.fGr, t, c));
+            if (!ADJOINT) gr[c] = s.ld(s.p(s.fGr, t, c));
             wc[c] = wp[c];
         }
         stage_weight(p, t, qg, wq);
@@ -1090,18 +1075,21 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
         uint64_t fixedR[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) fixedR[c] = fixed_from_right(S.bu[c] | S.bl[c], S.ru[c] | S.rl[c], T);
-        Sets drop;
-        drop.clear();
         double check = 0.0;
-        rounds_adjoint(s, p, S, fixedR, drop);
-        const bool stat_ok = rounds_multipliers(s, S, fixedR, drop, check);
-        bool dropped = false;
+        if (round == 0) {
+            // the interior-point iterate does not solve its working set's problem yet: its
+            // multipliers decide nothing, so the gradient is formed inside the Riccati sweep
+            rounds_riccati<true>(s, p, S, fixedR, run, check);
+            if (run && !finite_d(check)) run = false;
+        } else {
+            Sets drop;
+            drop.clear();
+            rounds_adjoint(s, p, S, fixedR, drop);
+            const bool stat_ok = rounds_multipliers(s, S, fixedR, drop, check);
+            bool dropped = false;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) dropped = dropped || (drop.bu[c] | drop.bl[c] | drop.ru[c] | drop.rl[c]) != 0;
-        const bool fin = finite_d(check);
-        // the first pass looks at the interior-point iterate, which is not on its working set:
-        // nothing is dropped or accepted on it
-        if (round > 0) {
+            for (int c = 0; c < 2; ++c) dropped = dropped || (drop.bu[c] | drop.bl[c] | drop.ru[c] | drop.rl[c]) != 0;
+            const bool fin = finite_d(check);
             if (run && fin && stat_ok && !violated && !dropped) { accepted = true; run = false; }
             if (run && (round >= max_rounds || !fin)) run = false;
 #pragma unroll
@@ -1109,13 +1097,12 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
                 S.bu[c] &= ~drop.bu[c]; S.bl[c] &= ~drop.bl[c];
                 S.ru[c] &= ~drop.ru[c]; S.rl[c] &= ~drop.rl[c];
             }
-        } else if (run && !fin) {
-            run = false;
+            if (!__any(run)) break;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) fixedR[c] = fixed_from_right(S.bu[c] | S.bl[c], S.ru[c] | S.rl[c], T);
+            rounds_riccati<false>(s, p, S, fixedR, run, check);
         }
         if (!__any(run)) break;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) fixedR[c] = fixed_from_right(S.bu[c] | S.bl[c], S.ru[c] | S.rl[c], T);
-        rounds_riccati(s, p, S, fixedR, run);
         Sets add, loose;
         add.clear();
         loose.clear();
