@@ -32,5 +32,8 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 30
  && pmc st_fetch FETCH_SIZE -- scripts/prof_solve.py dsr_ackermann 65536 5 30 \
  && pmc st_write WRITE_SIZE -- scripts/prof_solve.py dsr_ackermann 65536 5 30 \
  && pmc st_sq SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INSTS_SALU -- scripts/prof_solve.py dsr_ackermann 65536 3 30 \
+ && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lp_trace -o p -- python3 scripts/prof_loop.py > $OUT/lp_trace.log 2>&1 \
+ && pmc lp_fetch FETCH_SIZE -- scripts/prof_loop.py \
+ && pmc lp_write WRITE_SIZE -- scripts/prof_loop.py \
  && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sd_trace -o p -- python3 scripts/prof_solve.py dsr_diff 65536 5 30 > $OUT/sd_trace.log 2>&1 \
  && echo validate-done

@@ -120,6 +120,20 @@ pw = sq(["st_sq"], "k_solve_stage")
 if pw:
     json.dump({"kernel": "k_solve_stage<dual steer>", "T": 30, "batch": 65536, "csrc_sha": sha, "per_wave": pw, "how": how},
               open(os.path.join(PROF, f"{rnd}_stage_T30_sq_counters.json"), "w"), indent=1)
+# the kernels around the solve: reference window, advance, course builder
+st = kernel_stats("lp_trace", "p", f"{rnd}_loop_kernel_stats.csv")
+recs = {}
+for kern, alg in (("k_nearest_ref", 65536 * (32 + 8 + 176 + 4 + 24 * 6)), ("k_advance", 65536 * (8 * 4 * 2 + 8 * 4 + 4 + 4 + 2 + 16 + 4 + 16)),
+                  ("k_build_courses", None)):
+    t = traffic("lp_fetch", "lp_write", kern)
+    if t:
+        ns, calls = avg_ns(st, kern)
+        recs[kern] = {"avg_ns": ns, "launches": calls, "hbm_bytes_per_launch": t["bytes_per_launch"], "fetch_bytes": t["fetch_bytes"],
+                      "write_bytes": t["write_bytes"], "algorithmic_bytes": alg,
+                      "hbm_GBps": t["bytes_per_launch"] / ns if ns else None}
+if recs:
+    json.dump({"batch": 65536, "courses": 1024, "csrc_sha": sha, "kernels": recs, "how": how}, open(os.path.join(PROF, f"{rnd}_loop_kernels_traffic.json"), "w"), indent=1)
+    print("loop kernels", {k: (round(v["avg_ns"] / 1e3, 1), round(v["hbm_bytes_per_launch"] / 1e6, 1)) for k, v in recs.items()})
 for name in ("bench.json", "mixed4m.json"):
     p = os.path.join(OUT, name)
     if os.path.exists(p):
