@@ -104,34 +104,80 @@ __device__ __forceinline__ void load_dyn(const Store &s, int t, Dyn &d)
     for (int r = 0; r < 3; ++r) { d.b[r][0] = s.dyn(2 + 2 * r, t); d.b[r][1] = s.dyn(3 + 2 * r, t); }
 }
 
+// Every sweep over the stages is latency bound unless it is written for the memory system: a
+// load that follows a store in program order stays behind it (the compiler cannot tell that
+// the two do not overlap), so a stage body that interleaves them pays one memory round trip
+// per interleaving.  All sweeps therefore have the same shape: `load(t, rec)` issues every load
+// of stage t back to back into a record, `body(t, rec)` computes and stores; with kPrefetch the
+// record of the next stage is requested before the current stage is worked on, so that its
+// round trip overlaps the arithmetic and the stores (no stage reads what its predecessor in
+// the same sweep writes).  Stages first, first + step, ..., last.
+#ifndef MPCX_STAGE_PREFETCH
+#define MPCX_STAGE_PREFETCH 1
+#endif
+constexpr bool kPrefetch = MPCX_STAGE_PREFETCH != 0;
+
+template <class Rec, class LD, class BODY>
+__device__ __forceinline__ void sweep(int first, int last, int step, LD &&load, BODY &&body)
+{
+    if (kPrefetch) {
+        Rec cur;
+        load(first, cur);
+        _Pragma("nounroll") for (int t = first;; t += step) {
+            Rec nxt = cur;
+            const bool more = t != last;
+            if (more) load(t + step, nxt);
+            body(t, cur);
+            if (!more) break;
+            cur = nxt;
+        }
+    } else {
+        _Pragma("nounroll") for (int t = first;; t += step) {
+            Rec cur;
+            load(t, cur);
+            body(t, cur);
+            if (t == last) break;
+        }
+    }
+}
+
 // Forward rollout of the linearised dynamics, one stage per call; leaves
 // 2 Q_{t+1} (x_{t+1} - xref_{t+1}) for the adjoint sweep.
+struct RollIn {
+    double c[3], xr[3];   // affine term of the stage, reference of stage t + 1
+};
+__device__ __forceinline__ void load_roll(const Store &s, int t, RollIn &in)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { in.c[r] = s.dyn(8 + r, t); in.xr[r] = s.ld(s.f(s.fXr + r, t)); }
+}
 struct Roller {
     double x[3], qg;
     __device__ __forceinline__ void start(const Problem &p) { x[0] = p.x0[0]; x[1] = p.x0[1]; x[2] = p.x0[2]; qg = 1.0; }
-    __device__ __forceinline__ void step(const Store &s, const Problem &p, int t, double w0, double w1)
+    __device__ __forceinline__ void step(const Store &s, const Problem &p, int t, double w0, double w1, const Dyn &d,
+                                         const RollIn &in)
     {
         const int T = s.T;
-        Dyn d;
-        load_dyn(s, t, d);
-        const double n0 = x[0] + d.a02 * x[2] + d.b[0][0] * w0 + d.b[0][1] * w1 + s.dyn(8, t);
-        const double n1 = x[1] + d.a12 * x[2] + d.b[1][0] * w0 + d.b[1][1] * w1 + s.dyn(9, t);
-        const double n2 = x[2] + d.b[2][0] * w0 + d.b[2][1] * w1 + s.dyn(10, t);
+        const double n0 = x[0] + d.a02 * x[2] + d.b[0][0] * w0 + d.b[0][1] * w1 + in.c[0];
+        const double n1 = x[1] + d.a12 * x[2] + d.b[1][0] * w0 + d.b[1][1] * w1 + in.c[1];
+        const double n2 = x[2] + d.b[2][0] * w0 + d.b[2][1] * w1 + in.c[2];
         x[0] = n0; x[1] = n1; x[2] = n2;
         const int ts = t + 1;
         if (ts < T) qg *= p.growth;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double q = ts < T ? p.q[r] * qg : p.qf[r];
-            s.st(s.f(s.fQe + r, t), 2.0 * q * (x[r] - s.ld(s.f(s.fXr + r, ts - 1))));
+            s.st(s.f(s.fQe + r, t), 2.0 * q * (x[r] - in.xr[r]));
         }
     }
 };
 __device__ __forceinline__ void roll_zero(const Store &s, const Problem &p)
 {
+    struct Rec { Dyn d; RollIn r; };
     Roller ro;
     ro.start(p);
-    _Pragma("nounroll") for (int t = 0; t < s.T; ++t) ro.step(s, p, t, 0.0, 0.0);
+    sweep<Rec>(0, s.T - 1, 1, [&](int t, Rec &in) { load_dyn(s, t, in.d); load_roll(s, t, in.r); },
+               [&](int t, const Rec &in) { ro.step(s, p, t, 0.0, 0.0, in.d, in.r); });
 }
 
 // The backward sweeps of the interior point and of the active-set rounds have one shape: from
@@ -284,59 +330,69 @@ __device__ __forceinline__ void gains_of(const Store &s, int t, Gains &g)
 }
 
 // Forward sweep: the step dw_t = -(Lx dx_t + Lv dw_{t-1} + k_t), dx_{t+1} = A dx_t + B dw_t.
-// `sink(t, dw_t)` receives each stage's step in stage order.
-template <class F>
-__device__ __forceinline__ void forward(const Store &s, F &&sink)
+// `ldx(t, x)` loads whatever else the caller needs of stage t (type X) along with the gains;
+// `sink(t, dw_t, d, x)` receives each stage's step in stage order.
+template <class X, class LDX, class F>
+__device__ __forceinline__ void forward(const Store &s, LDX &&ldx, F &&sink)
 {
-    const int T = s.T;
+    struct Rec { double Lx[2][3], Lv[2][2], kv[2]; Dyn d; X x; };
     double dx[3] = {0.0, 0.0, 0.0}, vp[2] = {0.0, 0.0};
-    _Pragma("nounroll") for (int t = 0; t < T; ++t) {
-        double Lx[2][3], Lv[2][2];
-        load_gains(s, t, Lx, Lv);
-        Dyn d;
-        load_dyn(s, t, d);
-        double u[2];
+    sweep<Rec>(0, s.T - 1, 1,
+               [&](int t, Rec &in) {
+                   load_gains(s, t, in.Lx, in.Lv);
+                   load_dyn(s, t, in.d);
+                   in.kv[0] = s.ld(s.p(s.fKv, t, 0)); in.kv[1] = s.ld(s.p(s.fKv, t, 1));
+                   ldx(t, in.x);
+               },
+               [&](int t, const Rec &in) {
+                   const Dyn &d = in.d;
+                   double u[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-            u[c] = -(fma(Lx[c][0], dx[0], fma(Lx[c][1], dx[1], fma(Lx[c][2], dx[2],
-                     fma(Lv[c][0], vp[0], fma(Lv[c][1], vp[1], s.ld(s.p(s.fKv, t, c))))))));
-        const double n0 = dx[0] + d.a02 * dx[2] + d.b[0][0] * u[0] + d.b[0][1] * u[1];
-        const double n1 = dx[1] + d.a12 * dx[2] + d.b[1][0] * u[0] + d.b[1][1] * u[1];
-        const double n2 = dx[2] + d.b[2][0] * u[0] + d.b[2][1] * u[1];
-        dx[0] = n0; dx[1] = n1; dx[2] = n2;
-        vp[0] = u[0]; vp[1] = u[1];
-        sink(t, u);
-    }
+                   for (int c = 0; c < 2; ++c)
+                       u[c] = -(fma(in.Lx[c][0], dx[0], fma(in.Lx[c][1], dx[1], fma(in.Lx[c][2], dx[2],
+                                fma(in.Lv[c][0], vp[0], fma(in.Lv[c][1], vp[1], in.kv[c]))))));
+                   const double n0 = dx[0] + d.a02 * dx[2] + d.b[0][0] * u[0] + d.b[0][1] * u[1];
+                   const double n1 = dx[1] + d.a12 * dx[2] + d.b[1][0] * u[0] + d.b[1][1] * u[1];
+                   const double n2 = dx[2] + d.b[2][0] * u[0] + d.b[2][1] * u[1];
+                   dx[0] = n0; dx[1] = n1; dx[2] = n2;
+                   vp[0] = u[0]; vp[1] = u[1];
+                   sink(t, u, d, in.x);
+               });
 }
 
 // Adjoint state entering stage t's gradient: lambda_{t+1} = qe_t + A_{t+1}' lambda_{t+2}.
-__device__ __forceinline__ void adjoint_step(const Store &s, int t, double a02n, double a12n, double (&lam)[3])
+__device__ __forceinline__ void adjoint_step(const double (&qe)[3], double a02n, double a12n, double (&lam)[3])
 {
     const double l2 = fma(a02n, lam[0], fma(a12n, lam[1], lam[2]));   // a*n = 0 at the last stage
-    lam[0] = lam[0] + s.ld(s.f(s.fQe, t));
-    lam[1] = lam[1] + s.ld(s.f(s.fQe + 1, t));
-    lam[2] = l2 + s.ld(s.f(s.fQe + 2, t));
+    lam[0] = lam[0] + qe[0];
+    lam[1] = lam[1] + qe[1];
+    lam[2] = l2 + qe[2];
+}
+__device__ __forceinline__ void load_qe(const Store &s, int t, double (&qe)[3])
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) qe[r] = s.ld(s.f(s.fQe + r, t));
 }
 
 // Gradient at w = 0 (the g of the condensed problem), kept for the scale of the residual tests.
 __device__ __forceinline__ double gradient_at_zero(const Store &s, const Problem &p)
 {
+    struct Rec { Dyn d; double qe[3]; };
     double gmax = 0.0;
-    const int T = s.T;
     roll_zero(s, p);
     double lam[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0;
-    _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
-        Dyn d;
-        load_dyn(s, t, d);
-        adjoint_step(s, t, a02n, a12n, lam);
+    sweep<Rec>(s.T - 1, 0, -1, [&](int t, Rec &in) { load_dyn(s, t, in.d); load_qe(s, t, in.qe); },
+               [&](int t, const Rec &in) {
+                   const Dyn &d = in.d;
+                   adjoint_step(in.qe, a02n, a12n, lam);
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const double g = fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
-            gmax = dmax(gmax, fabs(g));
-            s.st(s.p(s.fG, t, c), g);
-        }
-        a02n = d.a02; a12n = d.a12;
-    }
+                   for (int c = 0; c < 2; ++c) {
+                       const double g = fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
+                       gmax = dmax(gmax, fabs(g));
+                       s.st(s.p(s.fG, t, c), g);
+                   }
+                   a02n = d.a02; a12n = d.a12;
+               });
     return gmax;
 }
 
@@ -433,43 +489,55 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         pl = hr ? fma(sm, k.irl[c], nl * yl * (yl - 1.0)) : 0.0;
     };
     auto update_and_roll = [&](bool do_roll) {
+        struct Rec { double w[2], da[2], dw[2], lu[2], ll[2], nu[2], nl[2]; Dyn d; RollIn r; };
         const bool upd = pend && run;
+        const bool any_upd = __any(upd);
         Roller ro;
         ro.start(p);
         double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0}, dapv[2] = {0.0, 0.0};
-        _Pragma("nounroll") for (int t = 0; t < T; ++t) {
-            double wc[2] = {s.ld(s.p(s.fW, t, 0)), s.ld(s.p(s.fW, t, 1))}, wnew[2];
-            if (__any(upd)) {   // old controls of the previous stage are kept for the rate terms
-                Slack k;
-                slacks(p, t, wc, wpv, k);
+        sweep<Rec>(0, T - 1, 1,
+                   [&](int t, Rec &in) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const double da = s.ld(s.p(s.fDwa, t, c)), dw = s.ld(s.p(s.fDw, t, c));
-                    const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
-                    const double nu = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0, nl = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
-                    double qu, ql, pu, pl;
-                    corr(k, t, c, lu, ll, nu, nl, da, dapv[c], qu, ql, pu, pl);
-                    const double dvv = dw - dpv[c];
-                    const double zu = dw * k.isu[c], zl = -dw * k.isl[c], vu = dvv * k.iru[c], vl = -dvv * k.irl[c];
-                    wnew[c] = upd ? fma(ap, dw, wc[c]) : wc[c];
-                    if (upd) {
-                        s.st(s.p(s.fW, t, c), wnew[c]);
-                        s.st(s.p(s.fLU, t, c), fma(ad, fma(lu, zu, qu - lu), lu));
-                        s.st(s.p(s.fLL, t, c), fma(ad, fma(ll, zl, ql - ll), ll));
-                        if (t > 0) {
-                            s.st(s.p(s.fNU, t - 1, c), fma(ad, fma(nu, vu, pu - nu), nu));
-                            s.st(s.p(s.fNL, t - 1, c), fma(ad, fma(nl, vl, pl - nl), nl));
-                        }
-                    }
-                    wpv[c] = wc[c];
-                    dpv[c] = dw;
-                    dapv[c] = da;
-                }
-            } else {
-                wnew[0] = wc[0]; wnew[1] = wc[1];
-            }
-            if (do_roll) ro.step(s, p, t, wnew[0], wnew[1]);
-        }
+                       for (int c = 0; c < 2; ++c) {
+                           in.w[c] = s.ld(s.p(s.fW, t, c));
+                           if (any_upd) {
+                               in.da[c] = s.ld(s.p(s.fDwa, t, c)); in.dw[c] = s.ld(s.p(s.fDw, t, c));
+                               in.lu[c] = s.ld(s.p(s.fLU, t, c)); in.ll[c] = s.ld(s.p(s.fLL, t, c));
+                               in.nu[c] = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0;
+                               in.nl[c] = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
+                           }
+                       }
+                       if (do_roll) { load_dyn(s, t, in.d); load_roll(s, t, in.r); }
+                   },
+                   [&](int t, const Rec &in) {
+                       double wnew[2] = {in.w[0], in.w[1]};
+                       if (any_upd) {   // old controls of the previous stage are kept for the rate terms
+                           Slack k;
+                           slacks(p, t, in.w, wpv, k);
+#pragma unroll
+                           for (int c = 0; c < 2; ++c) {
+                               const double da = in.da[c], dw = in.dw[c], lu = in.lu[c], ll = in.ll[c], nu = in.nu[c], nl = in.nl[c];
+                               double qu, ql, pu, pl;
+                               corr(k, t, c, lu, ll, nu, nl, da, dapv[c], qu, ql, pu, pl);
+                               const double dvv = dw - dpv[c];
+                               const double zu = dw * k.isu[c], zl = -dw * k.isl[c], vu = dvv * k.iru[c], vl = -dvv * k.irl[c];
+                               wnew[c] = upd ? fma(ap, dw, in.w[c]) : in.w[c];
+                               if (upd) {
+                                   s.st(s.p(s.fW, t, c), wnew[c]);
+                                   s.st(s.p(s.fLU, t, c), fma(ad, fma(lu, zu, qu - lu), lu));
+                                   s.st(s.p(s.fLL, t, c), fma(ad, fma(ll, zl, ql - ll), ll));
+                                   if (t > 0) {
+                                       s.st(s.p(s.fNU, t - 1, c), fma(ad, fma(nu, vu, pu - nu), nu));
+                                       s.st(s.p(s.fNL, t - 1, c), fma(ad, fma(nl, vl, pl - nl), nl));
+                                   }
+                               }
+                               wpv[c] = in.w[c];
+                               dpv[c] = dw;
+                               dapv[c] = da;
+                           }
+                       }
+                       if (do_roll) ro.step(s, p, t, wnew[0], wnew[1], in.d, in.r);
+                   });
         pend = false;
     };
     for (int it = 0;; ++it) {
@@ -478,6 +546,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         // backward: gradient, residuals, Riccati gains, feed-forward of the predictor (r = -hw)
         double musum = 0.0, rdmax = 0.0, scl = 0.0;
         {
+            struct Rec { Dyn d; double wp[2], nup[2], nlp[2], qe[3], lu[2], ll[2], g[2]; };
             Riccati R;
             R.terminal(p.qf);
             double lam[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0;
@@ -485,47 +554,51 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
             double qg = 1.0;
             for (int t = 1; t < T; ++t) qg *= p.growth;        // growth^(T - 1)
             double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
-            _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
-                Dyn d;
-                load_dyn(s, t, d);
-                double wp[2] = {0.0, 0.0}, nup[2] = {0.0, 0.0}, nlp[2] = {0.0, 0.0};
-                if (t > 0) {
+            sweep<Rec>(T - 1, 0, -1,
+                       [&](int t, Rec &in) {
+                           load_dyn(s, t, in.d);
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        wp[c] = s.ld(s.p(s.fW, t - 1, c));
-                        nup[c] = s.ld(s.p(s.fNU, t - 1, c));
-                        nlp[c] = s.ld(s.p(s.fNL, t - 1, c));
-                    }
-                }
-                Slack k;
-                slacks(p, t, wc, wp, k);
-                adjoint_step(s, t, a02n, a12n, lam);
-                double wr[2], we[2], wq[3], r[2];
+                           for (int c = 0; c < 2; ++c) {
+                               in.wp[c] = t > 0 ? s.ld(s.p(s.fW, t - 1, c)) : 0.0;
+                               in.nup[c] = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0;
+                               in.nlp[c] = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
+                               in.lu[c] = s.ld(s.p(s.fLU, t, c)); in.ll[c] = s.ld(s.p(s.fLL, t, c));
+                               in.g[c] = s.ld(s.p(s.fG, t, c));
+                           }
+                           load_qe(s, t, in.qe);
+                       },
+                       [&](int t, const Rec &in) {
+                           const Dyn &d = in.d;
+                           const double (&wp)[2] = in.wp, (&nup)[2] = in.nup, (&nlp)[2] = in.nlp;
+                           Slack k;
+                           slacks(p, t, wc, wp, k);
+                           adjoint_step(in.qe, a02n, a12n, lam);
+                           double wr[2], we[2], wq[3], r[2];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
-                    const double hw = input_cost_grad(p, c, t, T, wp[c], wc[c], wn[c])
-                                      + fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
-                    const double ctl = (lu - ll) + (nup[c] - nlp[c]) - dnun[c];
-                    if (p.hb(t, c)) musum = fma(k.su[c], lu, fma(k.sl[c], ll, musum));
-                    if (p.hr(c) && t > 0) musum = fma(k.ru[c], nup[c], fma(k.rl[c], nlp[c], musum));
-                    rdmax = dmax(rdmax, fabs(hw + ctl));
-                    const double g = s.ld(s.p(s.fG, t, c));
-                    scl = dmax(scl, dmax(fabs(hw - g), dmax(fabs(g), fabs(ctl))));
-                    wr[c] = 2.0 * p.rw[c] + fma(lu, k.isu[c], ll * k.isl[c]);
-                    we[c] = t > 0 ? 2.0 * p.rdw[c] + fma(nup[c], k.iru[c], nlp[c] * k.irl[c]) : 0.0;
-                    r[c] = -hw;
-                    dnun[c] = nup[c] - nlp[c];
-                    wn[c] = wc[c];
-                    wc[c] = wp[c];
-                }
-                stage_weight(p, t, qg, wq);
-                Gains gn;
-                riccati_matrix_step(s, t, d, wr, we, wq, R, gn, run);   // touches the matrices of R only
-                riccati_vector_step(s, t, d, r, gn.Lx, gn.Lv, gn.Hi, R, run);
-                a02n = d.a02; a12n = d.a12;
-                qg = qg / p.growth;
-            }
+                           for (int c = 0; c < 2; ++c) {
+                               const double lu = in.lu[c], ll = in.ll[c];
+                               const double hw = input_cost_grad(p, c, t, T, wp[c], wc[c], wn[c])
+                                                 + fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
+                               const double ctl = (lu - ll) + (nup[c] - nlp[c]) - dnun[c];
+                               if (p.hb(t, c)) musum = fma(k.su[c], lu, fma(k.sl[c], ll, musum));
+                               if (p.hr(c) && t > 0) musum = fma(k.ru[c], nup[c], fma(k.rl[c], nlp[c], musum));
+                               rdmax = dmax(rdmax, fabs(hw + ctl));
+                               const double g = in.g[c];
+                               scl = dmax(scl, dmax(fabs(hw - g), dmax(fabs(g), fabs(ctl))));
+                               wr[c] = 2.0 * p.rw[c] + fma(lu, k.isu[c], ll * k.isl[c]);
+                               we[c] = t > 0 ? 2.0 * p.rdw[c] + fma(nup[c], k.iru[c], nlp[c] * k.irl[c]) : 0.0;
+                               r[c] = -hw;
+                               dnun[c] = nup[c] - nlp[c];
+                               wn[c] = wc[c];
+                               wc[c] = wp[c];
+                           }
+                           stage_weight(p, t, qg, wq);
+                           Gains gn;
+                           riccati_matrix_step(s, t, d, wr, we, wq, R, gn, run);   // touches the matrices of R only
+                           riccati_vector_step(s, t, d, r, gn.Lx, gn.Lv, gn.Hi, R, run);
+                           a02n = d.a02; a12n = d.a12;
+                           qg = qg / p.growth;
+                       });
         }
         const double mu = musum * inv_m;
         const double scale = dmax(1.0, scl) + 1.0;
@@ -547,11 +620,12 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         // forward: predictor step and its step lengths
         double rp = 0.0, rdm = 1.0;
         {
+            struct X { double w[2]; };
             double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0};
-            forward(s, [&](int t, const double (&u)[2]) {
-                double wc[2] = {s.ld(s.p(s.fW, t, 0)), s.ld(s.p(s.fW, t, 1))};
+            forward<X>(s, [&](int t, X &x) { x.w[0] = s.ld(s.p(s.fW, t, 0)); x.w[1] = s.ld(s.p(s.fW, t, 1)); },
+                       [&](int t, const double (&u)[2], const Dyn &, const X &x) {
                 Slack k;
-                slacks(p, t, wc, wpv, k);
+                slacks(p, t, x.w, wpv, k);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     if (run) s.st(s.p(s.fDwa, t, c), u[c]);
@@ -560,7 +634,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                     const double yu = dva * k.iru[c], yl = -dva * k.irl[c];
                     if (p.hb(t, c)) { rp = dmax(rp, dmax(xu, xl)); rdm = dmax(rdm, dmax(1.0 - xu, 1.0 - xl)); }
                     if (p.hr(c) && t > 0) { rp = dmax(rp, dmax(yu, yl)); rdm = dmax(rdm, dmax(1.0 - yu, 1.0 - yl)); }
-                    wpv[c] = wc[c];
+                    wpv[c] = x.w[c];
                     dpv[c] = u[c];
                 }
             });
@@ -570,56 +644,65 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         if (run) sm = back * back * back * mu;
         // backward: feed-forward of the corrector, r_t = -(C' q)_t
         {
+            struct Rec { Dyn d; double wp[2], dp[2], nup[2], nlp[2], lu[2], ll[2]; Gains g; };
             Riccati R;
             R.terminal(p.qf);
             double trn[2] = {0.0, 0.0};    // (pu - pl) of constraint (t, t + 1)
             double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
             double dc[2] = {s.ld(s.p(s.fDwa, T - 1, 0)), s.ld(s.p(s.fDwa, T - 1, 1))};
-            _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
-                Dyn d;
-                load_dyn(s, t, d);
-                double wp[2] = {0.0, 0.0}, dp[2] = {0.0, 0.0}, nup[2] = {0.0, 0.0}, nlp[2] = {0.0, 0.0};
-                if (t > 0) {
+            sweep<Rec>(T - 1, 0, -1,
+                       [&](int t, Rec &in) {
+                           load_dyn(s, t, in.d);
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        wp[c] = s.ld(s.p(s.fW, t - 1, c));
-                        dp[c] = s.ld(s.p(s.fDwa, t - 1, c));
-                        nup[c] = s.ld(s.p(s.fNU, t - 1, c));
-                        nlp[c] = s.ld(s.p(s.fNL, t - 1, c));
-                    }
-                }
-                Slack k;
-                slacks(p, t, wc, wp, k);
-                double r[2];
+                           for (int c = 0; c < 2; ++c) {
+                               in.wp[c] = t > 0 ? s.ld(s.p(s.fW, t - 1, c)) : 0.0;
+                               in.dp[c] = t > 0 ? s.ld(s.p(s.fDwa, t - 1, c)) : 0.0;
+                               in.nup[c] = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0;
+                               in.nlp[c] = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
+                               in.lu[c] = s.ld(s.p(s.fLU, t, c)); in.ll[c] = s.ld(s.p(s.fLL, t, c));
+                           }
+                           gains_of(s, t, in.g);
+                       },
+                       [&](int t, const Rec &in) {
+                           Slack k;
+                           slacks(p, t, wc, in.wp, k);
+                           double r[2];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    double qu, ql, pu, pl;
-                    corr(k, t, c, s.ld(s.p(s.fLU, t, c)), s.ld(s.p(s.fLL, t, c)), nup[c], nlp[c], dc[c], dp[c], qu, ql, pu, pl);
-                    r[c] = -((qu - ql) + (pu - pl) - trn[c]);
-                    trn[c] = pu - pl;
-                    wc[c] = wp[c];
-                    dc[c] = dp[c];
-                }
-                Gains gn;
-                gains_of(s, t, gn);
-                riccati_vector_step(s, t, d, r, gn.Lx, gn.Lv, gn.Hi, R, run);
-            }
+                           for (int c = 0; c < 2; ++c) {
+                               double qu, ql, pu, pl;
+                               corr(k, t, c, in.lu[c], in.ll[c], in.nup[c], in.nlp[c], dc[c], in.dp[c], qu, ql, pu, pl);
+                               r[c] = -((qu - ql) + (pu - pl) - trn[c]);
+                               trn[c] = pu - pl;
+                               wc[c] = in.wp[c];
+                               dc[c] = in.dp[c];
+                           }
+                           riccati_vector_step(s, t, in.d, r, in.g.Lx, in.g.Lv, in.g.Hi, R, run);
+                       });
         }
         // forward: full step, its step lengths
         double rp2 = 0.0, rd2 = 0.0, chk = 0.0;
         {
+            struct X { double w[2], da[2], lu[2], ll[2], nu[2], nl[2]; };
             double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0}, dapv[2] = {0.0, 0.0};
-            forward(s, [&](int t, const double (&uc)[2]) {
-                double wc[2] = {s.ld(s.p(s.fW, t, 0)), s.ld(s.p(s.fW, t, 1))};
+            forward<X>(s,
+                       [&](int t, X &x) {
+#pragma unroll
+                           for (int c = 0; c < 2; ++c) {
+                               x.w[c] = s.ld(s.p(s.fW, t, c)); x.da[c] = s.ld(s.p(s.fDwa, t, c));
+                               x.lu[c] = s.ld(s.p(s.fLU, t, c)); x.ll[c] = s.ld(s.p(s.fLL, t, c));
+                               x.nu[c] = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0;
+                               x.nl[c] = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
+                           }
+                       },
+                       [&](int t, const double (&uc)[2], const Dyn &, const X &x) {
                 Slack k;
-                slacks(p, t, wc, wpv, k);
+                slacks(p, t, x.w, wpv, k);
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
-                    const double da = s.ld(s.p(s.fDwa, t, c));
+                    const double da = x.da[c];
                     const double dw = da + uc[c];
                     if (run) s.st(s.p(s.fDw, t, c), dw);
-                    const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
-                    const double nu = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0, nl = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
+                    const double lu = x.lu[c], ll = x.ll[c], nu = x.nu[c], nl = x.nl[c];
                     double qu, ql, pu, pl;
                     corr(k, t, c, lu, ll, nu, nl, da, dapv[c], qu, ql, pu, pl);
                     const double dvv = dw - dpv[c];
@@ -637,7 +720,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                         chk += dnu + dnl;
                     }
                     chk += dw;
-                    wpv[c] = wc[c];
+                    wpv[c] = x.w[c];
                     dpv[c] = dw;
                     dapv[c] = da;
                 }
@@ -704,56 +787,63 @@ constexpr double kFeasTol = 1e-12;    // constraint violation that enters the wo
 __device__ __forceinline__ void rounds_adjoint(const Store &s, const Problem &p, const Sets &S, const uint64_t (&fixedR)[2],
                                                Sets &drop)
 {
+    struct Rec { Dyn d; double qe[3], xr[3], wp[2]; };
     const int T = s.T;
     double lam[3] = {0.0, 0.0, 0.0}, la[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0;
     double wn[2] = {0.0, 0.0}, curn[2] = {0.0, 0.0}, grn[2] = {0.0, 0.0}, magn[2] = {0.0, 0.0};
     double qg = 1.0;
     for (int t = 1; t < T; ++t) qg *= p.growth;        // growth^(T - 1)
     double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
-    _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
-        Dyn d;
-        load_dyn(s, t, d);
-        // adjoint and the size of its terms
-        {
-            const double l2 = fma(a02n, lam[0], fma(a12n, lam[1], lam[2]));
-            const double m2 = fma(fabs(a02n), la[0], fma(fabs(a12n), la[1], la[2]));
-            double qe[3], qa[3];
+    sweep<Rec>(T - 1, 0, -1,
+               [&](int t, Rec &in) {
+                   load_dyn(s, t, in.d);
+                   load_qe(s, t, in.qe);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                qe[r] = s.ld(s.f(s.fQe + r, t));
-                const double q = t + 1 < T ? p.q[r] * qg * p.growth : p.qf[r];
-                qa[r] = fabs(qe[r]) + 4.0 * q * fabs(s.ld(s.f(s.fXr + r, t)));
-            }
-            lam[0] += qe[0]; lam[1] += qe[1]; lam[2] = l2 + qe[2];
-            la[0] += qa[0]; la[1] += qa[1]; la[2] = m2 + qa[2];
-        }
-        double wp[2] = {0.0, 0.0};
-        if (t > 0) { wp[0] = s.ld(s.p(s.fW, t - 1, 0)); wp[1] = s.ld(s.p(s.fW, t - 1, 1)); }
+                   for (int r = 0; r < 3; ++r) in.xr[r] = s.ld(s.f(s.fXr + r, t));
+                   in.wp[0] = t > 0 ? s.ld(s.p(s.fW, t - 1, 0)) : 0.0;
+                   in.wp[1] = t > 0 ? s.ld(s.p(s.fW, t - 1, 1)) : 0.0;
+               },
+               [&](int t, const Rec &in) {
+                   const Dyn &d = in.d;
+                   const double (&wp)[2] = in.wp;
+                   // adjoint and the size of its terms
+                   {
+                       const double l2 = fma(a02n, lam[0], fma(a12n, lam[1], lam[2]));
+                       const double m2 = fma(fabs(a02n), la[0], fma(fabs(a12n), la[1], la[2]));
+                       double qa[3];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const double gr = input_cost_grad(p, c, t, T, wp[c], wc[c], wn[c])
-                              + fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
-            double mag = fabs(2.0 * p.rw[c] * wc[c]) + fma(fabs(d.b[0][c]), la[0], fma(fabs(d.b[1][c]), la[1], fabs(d.b[2][c]) * la[2]));
-            if (t > 0) mag += fabs(2.0 * p.rdw[c] * (wc[c] - wp[c]));
-            if (t + 1 < T) mag += fabs(2.0 * p.rdw[c] * (wn[c] - wc[c]));
-            const bool up = bit(S.ru[c], t), dn = bit(S.rl[c], t);
-            double cur = 0.0;
-            if ((up || dn) && !bit(fixedR[c], t + 1)) {
-                cur = curn[c] - grn[c];
-                const double tol = kNoiseTol * (dmax(mag, magn[c]) + 1.0);
-                if (up && cur < -tol) drop.ru[c] |= one(t);
-                if (dn && -cur < -tol) drop.rl[c] |= one(t);
-            }
-            s.st(s.p(s.fGr, t, c), gr);
-            s.st(s.p(s.fCur, t, c), cur);
-            s.st(s.p(s.fMag, t, c), mag);
-            curn[c] = cur; grn[c] = gr; magn[c] = mag;
-            wn[c] = wc[c];
-            wc[c] = wp[c];
-        }
-        a02n = d.a02; a12n = d.a12;
-        qg = qg / p.growth;
-    }
+                       for (int r = 0; r < 3; ++r) {
+                           const double q = t + 1 < T ? p.q[r] * qg * p.growth : p.qf[r];
+                           qa[r] = fabs(in.qe[r]) + 4.0 * q * fabs(in.xr[r]);
+                       }
+                       lam[0] += in.qe[0]; lam[1] += in.qe[1]; lam[2] = l2 + in.qe[2];
+                       la[0] += qa[0]; la[1] += qa[1]; la[2] = m2 + qa[2];
+                   }
+#pragma unroll
+                   for (int c = 0; c < 2; ++c) {
+                       const double gr = input_cost_grad(p, c, t, T, wp[c], wc[c], wn[c])
+                                         + fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
+                       double mag = fabs(2.0 * p.rw[c] * wc[c]) + fma(fabs(d.b[0][c]), la[0], fma(fabs(d.b[1][c]), la[1], fabs(d.b[2][c]) * la[2]));
+                       if (t > 0) mag += fabs(2.0 * p.rdw[c] * (wc[c] - wp[c]));
+                       if (t + 1 < T) mag += fabs(2.0 * p.rdw[c] * (wn[c] - wc[c]));
+                       const bool up = bit(S.ru[c], t), dn = bit(S.rl[c], t);
+                       double cur = 0.0;
+                       if ((up || dn) && !bit(fixedR[c], t + 1)) {
+                           cur = curn[c] - grn[c];
+                           const double tol = kNoiseTol * (dmax(mag, magn[c]) + 1.0);
+                           if (up && cur < -tol) drop.ru[c] |= one(t);
+                           if (dn && -cur < -tol) drop.rl[c] |= one(t);
+                       }
+                       s.st(s.p(s.fGr, t, c), gr);
+                       s.st(s.p(s.fCur, t, c), cur);
+                       s.st(s.p(s.fMag, t, c), mag);
+                       curn[c] = cur; grn[c] = gr; magn[c] = mag;
+                       wn[c] = wc[c];
+                       wc[c] = wp[c];
+                   }
+                   a02n = d.a02; a12n = d.a12;
+                   qg = qg / p.growth;
+               });
 }
 
 // Forward pass over what rounds_adjoint stored: the remaining multipliers from
@@ -770,13 +860,21 @@ __device__ __forceinline__ void rounds_adjoint(const Store &s, const Problem &p,
 __device__ __forceinline__ bool rounds_multipliers(const Store &s, const Sets &S, const uint64_t (&fixedR)[2], Sets &drop,
                                                    double &check)
 {
+    struct Rec { double gr[2], cur[2], mag[2]; };
     const int T = s.T;
     bool stat_ok = true;
     double flo[2] = {0.0, 0.0}, fhi[2] = {0.0, 0.0}, magp[2] = {0.0, 0.0};
-    _Pragma("nounroll") for (int t = 0; t < T; ++t) {
+    sweep<Rec>(0, T - 1, 1,
+               [&](int t, Rec &in) {
+#pragma unroll
+                   for (int c = 0; c < 2; ++c) {
+                       in.gr[c] = s.ld(s.p(s.fGr, t, c)); in.cur[c] = s.ld(s.p(s.fCur, t, c)); in.mag[c] = s.ld(s.p(s.fMag, t, c));
+                   }
+               },
+               [&](int t, const Rec &in) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const double gr = s.ld(s.p(s.fGr, t, c)), cur = s.ld(s.p(s.fCur, t, c)), mag = s.ld(s.p(s.fMag, t, c));
+            const double gr = in.gr[c], cur = in.cur[c], mag = in.mag[c];
             check += gr + cur;
             const bool fx = bit(fixedR[c], t);
             const bool tie_prev = t > 0 && (bit(S.ru[c], t - 1) || bit(S.rl[c], t - 1));
@@ -808,7 +906,7 @@ __device__ __forceinline__ bool rounds_multipliers(const Store &s, const Sets &S
             flo[c] = nlo; fhi[c] = nhi;
             magp[c] = mag;
         }
-    }
+               });
     return stat_ok;
 }
 
@@ -834,16 +932,23 @@ __device__ __forceinline__ void rounds_riccati(const Store &s, const Problem &p,
     for (int t = 1; t < T; ++t) qg *= p.growth;
     double tau[2] = {0.0, 0.0};
     double lam[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0, wn[2] = {0.0, 0.0};
+    struct Rec { Dyn d; double wp[2], qe[3], gr[2]; };
     double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
-    _Pragma("nounroll") for (int t = T - 1; t >= 0; --t) {
-        Dyn d;
-        load_dyn(s, t, d);
-        double wp[2] = {0.0, 0.0};
-        if (t > 0) { wp[0] = s.ld(s.p(s.fW, t - 1, 0)); wp[1] = s.ld(s.p(s.fW, t - 1, 1)); }
+    sweep<Rec>(T - 1, 0, -1,
+               [&](int t, Rec &in) {
+                   load_dyn(s, t, in.d);
+                   in.wp[0] = t > 0 ? s.ld(s.p(s.fW, t - 1, 0)) : 0.0;
+                   in.wp[1] = t > 0 ? s.ld(s.p(s.fW, t - 1, 1)) : 0.0;
+                   if (ADJOINT) load_qe(s, t, in.qe);
+                   else { in.gr[0] = s.ld(s.p(s.fGr, t, 0)); in.gr[1] = s.ld(s.p(s.fGr, t, 1)); }
+               },
+               [&](int t, const Rec &in) {
+        const Dyn &d = in.d;
+        const double (&wp)[2] = in.wp;
         double sig[2], o[2], wr[2], we[2], wq[3], gr[2];
         bool fr[2];
         if (ADJOINT) {
-            adjoint_step(s, t, a02n, a12n, lam);
+            adjoint_step(in.qe, a02n, a12n, lam);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 gr[c] = input_cost_grad(p, c, t, T, wp[c], wc[c], wn[c])
@@ -874,7 +979,7 @@ __device__ __forceinline__ void rounds_riccati(const Store &s, const Problem &p,
             }
             wr[c] = 2.0 * p.rw[c];
             we[c] = t > 0 ? 2.0 * p.rdw[c] : 0.0;
-            if (!ADJOINT) gr[c] = s.ld(s.p(s.fGr, t, c));
+            if (!ADJOINT) gr[c] = in.gr[c];
             wc[c] = wp[c];
         }
         stage_weight(p, t, qg, wq);
@@ -988,7 +1093,7 @@ __device__ __forceinline__ void rounds_riccati(const Store &s, const Problem &p,
             R = N;
         }
         qg = qg / p.growth;
-    }
+               });
 }
 
 // Forward sweep of a round: the step of the working-set problem, the new controls (a control on
@@ -999,14 +1104,16 @@ __device__ __forceinline__ void rounds_riccati(const Store &s, const Problem &p,
 __device__ __forceinline__ void rounds_forward(const Store &s, const Problem &p, const Sets &S, bool run, Sets &add,
                                                Sets &loose, double &check)
 {
+    struct X { double w[2]; RollIn r; };
     double wpn[2] = {0.0, 0.0};   // new controls of the previous stage
     Roller ro;
     ro.start(p);
-    forward(s, [&](int t, const double (&u)[2]) {
+    forward<X>(s, [&](int t, X &x) { x.w[0] = s.ld(s.p(s.fW, t, 0)); x.w[1] = s.ld(s.p(s.fW, t, 1)); load_roll(s, t, x.r); },
+               [&](int t, const double (&u)[2], const Dyn &d, const X &x) {
         double wst[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            double wnew = s.ld(s.p(s.fW, t, c)) + u[c];
+            double wnew = x.w[c] + u[c];
             if (bit(S.bu[c], t)) wnew = p.hi(t, c);
             else if (bit(S.bl[c], t)) wnew = p.lo(t, c);
             wst[c] = wnew;
@@ -1025,7 +1132,7 @@ __device__ __forceinline__ void rounds_forward(const Store &s, const Problem &p,
             if (run) s.st(s.p(s.fW, t, c), wnew);
             wpn[c] = wnew;
         }
-        ro.step(s, p, t, wst[0], wst[1]);   // for the next round's adjoint sweep
+        ro.step(s, p, t, wst[0], wst[1], d, x.r);   // for the next round's adjoint sweep
     });
 }
 
@@ -1041,31 +1148,40 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
     S.clear();
     // working set off the iterate (multiplier above slack), backup of the controls, rollout
     if (__any(run)) {
+        struct Rec { double w[2], lu[2], ll[2], nu[2], nl[2]; Dyn d; RollIn r; };
         Roller ro;
         ro.start(p);
         double wpv[2] = {0.0, 0.0};
-        _Pragma("nounroll") for (int t = 0; t < T; ++t) {
-            double wst[2];
+        sweep<Rec>(0, T - 1, 1,
+                   [&](int t, Rec &in) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const double wc = s.ld(s.p(s.fW, t, c));
-                wst[c] = wc;
-                if (run) s.st(s.p(s.fBak, t, c), wc);
-                if (p.hb(t, c)) {
-                    const double lu = s.ld(s.p(s.fLU, t, c)), ll = s.ld(s.p(s.fLL, t, c));
-                    if (lu > p.hi(t, c) - wc) S.bu[c] |= one(t);
-                    else if (ll > wc - p.lo(t, c)) S.bl[c] |= one(t);
-                }
-                if (t > 0 && p.hr(c)) {
-                    const double dv = wc - wpv[c];
-                    const double nu = s.ld(s.p(s.fNU, t - 1, c)), nl = s.ld(s.p(s.fNL, t - 1, c));
-                    if (nu > p.fb.rr[c] - dv) S.ru[c] |= one(t - 1);
-                    else if (nl > p.fb.rr[c] + dv) S.rl[c] |= one(t - 1);
-                }
-                wpv[c] = wc;
-            }
-            ro.step(s, p, t, wst[0], wst[1]);
-        }
+                       for (int c = 0; c < 2; ++c) {
+                           in.w[c] = s.ld(s.p(s.fW, t, c));
+                           in.lu[c] = s.ld(s.p(s.fLU, t, c)); in.ll[c] = s.ld(s.p(s.fLL, t, c));
+                           in.nu[c] = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0;
+                           in.nl[c] = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
+                       }
+                       load_dyn(s, t, in.d);
+                       load_roll(s, t, in.r);
+                   },
+                   [&](int t, const Rec &in) {
+#pragma unroll
+                       for (int c = 0; c < 2; ++c) {
+                           const double wc = in.w[c];
+                           if (run) s.st(s.p(s.fBak, t, c), wc);
+                           if (p.hb(t, c)) {
+                               if (in.lu[c] > p.hi(t, c) - wc) S.bu[c] |= one(t);
+                               else if (in.ll[c] > wc - p.lo(t, c)) S.bl[c] |= one(t);
+                           }
+                           if (t > 0 && p.hr(c)) {
+                               const double dv = wc - wpv[c];
+                               if (in.nu[c] > p.fb.rr[c] - dv) S.ru[c] |= one(t - 1);
+                               else if (in.nl[c] > p.fb.rr[c] + dv) S.rl[c] |= one(t - 1);
+                           }
+                           wpv[c] = wc;
+                       }
+                       ro.step(s, p, t, in.w[0], in.w[1], in.d, in.r);
+                   });
     }
     bool accepted = false;
     bool violated = true;   // no point of this working set has been checked yet
@@ -1118,11 +1234,14 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
             S.rl[c] = ((S.rl[c] & ~loose.rl[c]) | add.rl[c]) & ~add.ru[c];
         }
     }
-    if (ran && !accepted)
-        for (int t = 0; t < T; ++t) {
-            s.st(s.p(s.fW, t, 0), s.ld(s.p(s.fBak, t, 0)));
-            s.st(s.p(s.fW, t, 1), s.ld(s.p(s.fBak, t, 1)));
-        }
+    if (__any(ran && !accepted)) {
+        struct Rec { double w[2]; };
+        const bool back = ran && !accepted;
+        sweep<Rec>(0, T - 1, 1, [&](int t, Rec &in) { in.w[0] = s.ld(s.p(s.fBak, t, 0)); in.w[1] = s.ld(s.p(s.fBak, t, 1)); },
+                   [&](int t, const Rec &in) {
+                       if (back) { s.st(s.p(s.fW, t, 0), in.w[0]); s.st(s.p(s.fW, t, 1), in.w[1]); }
+                   });
+    }
     return accepted;
 }
 
