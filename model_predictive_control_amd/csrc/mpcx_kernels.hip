@@ -526,8 +526,11 @@ constexpr int kStageAttempts = 3;
 __device__ const double kStageSwitchMu[kStageAttempts] = {kSwitchMu, 1e-9, 0.0};
 __device__ const int kStageRounds[kStageAttempts] = {MPCX_STAGE_R0, 6, 6};
 
+#ifndef MPCX_STAGE_OCC
+#define MPCX_STAGE_OCC 1   // wavefronts per SIMD the register budget is set for
+#endif
 template <int MODEL>
-__global__ __launch_bounds__(kWave, 2) void k_solve_stage(SolveArgs a, double *ws)
+__global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs a, double *ws)
 {
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     const mpcx_variant &v = a.v;

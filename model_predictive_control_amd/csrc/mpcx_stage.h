@@ -41,7 +41,8 @@ struct Store {
         fW = 19,
         fLU = 21, fLL = 23,
         fNU = 25, fNL = 27,   // rate multipliers: the record of stage t holds constraint (t, t + 1)
-        fLx = 29, fLv = 35, fHi = 39,   // Riccati gains
+        fLx = 29, fLv = 35,   // Riccati gains
+        fDq = 39,        // 2 Q_{t+1} (change of x_{t+1} along the step): the rollout of the next iterate without rolling
         fKv = 42,        // feed-forward of the current right-hand side
         fDwa = 44, fDw = 46,
         fBak = 48,       // controls before the active-set rounds
@@ -261,7 +262,6 @@ __device__ __forceinline__ void riccati_matrix_step(const Store &s, int t, const
             s.st(s.f(s.fLv + c * 2, t), Lv[c][0]);
             s.st(s.f(s.fLv + c * 2 + 1, t), Lv[c][1]);
         }
-        s.st(s.f(s.fHi, t), i00); s.st(s.f(s.fHi + 1, t), i01); s.st(s.f(s.fHi + 2, t), i11);
     }
     if (t == 0) return;
     // A' Pxx A
@@ -323,15 +323,10 @@ __device__ __forceinline__ void load_gains(const Store &s, int t, double (&Lx)[2
     }
 }
 
-__device__ __forceinline__ void gains_of(const Store &s, int t, Gains &g)
-{
-    load_gains(s, t, g.Lx, g.Lv);
-    g.Hi[0] = s.ld(s.f(s.fHi, t)); g.Hi[1] = s.ld(s.f(s.fHi + 1, t)); g.Hi[2] = s.ld(s.f(s.fHi + 2, t));
-}
-
 // Forward sweep: the step dw_t = -(Lx dx_t + Lv dw_{t-1} + k_t), dx_{t+1} = A dx_t + B dw_t.
 // `ldx(t, x)` loads whatever else the caller needs of stage t (type X) along with the gains;
-// `sink(t, dw_t, d, x)` receives each stage's step in stage order.
+// `sink(t, dw_t, dx_{t+1}, d, x)` receives each stage's step and the state step it leads to, in
+// stage order.
 template <class X, class LDX, class F>
 __device__ __forceinline__ void forward(const Store &s, LDX &&ldx, F &&sink)
 {
@@ -356,7 +351,7 @@ __device__ __forceinline__ void forward(const Store &s, LDX &&ldx, F &&sink)
                    const double n2 = dx[2] + d.b[2][0] * u[0] + d.b[2][1] * u[1];
                    dx[0] = n0; dx[1] = n1; dx[2] = n2;
                    vp[0] = u[0]; vp[1] = u[1];
-                   sink(t, u, d, in.x);
+                   sink(t, u, dx, d, in.x);
                });
 }
 
@@ -472,8 +467,10 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
     }
     status = MPCX_ST_FAILED;
     iters = 0;
-    // step of the previous iteration, applied at the start of the next one in the same sweep
-    // that rolls the dynamics forward (and once more on the way out)
+    // Step of the previous iteration (primal and dual step lengths, centring term): applied at
+    // the start of the next iteration, inside the backward sweep that factorises, because only
+    // then are the step lengths known.  The rollout is not repeated for the new iterate: the
+    // forward sweep that found the step left 2 Q dx along it, and x is linear in w.
     bool pend = false;
     double ap = 0.0, ad = 0.0, sm = 0.0;
     // corrector terms of one stage: q for the box of stage t, p for the rate constraint (t - 1, t)
@@ -488,72 +485,51 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         pu = hr ? fma(sm, k.iru[c], nu * yu * (yu - 1.0)) : 0.0;
         pl = hr ? fma(sm, k.irl[c], nl * yl * (yl - 1.0)) : 0.0;
     };
-    auto update_and_roll = [&](bool do_roll) {
-        struct Rec { double w[2], da[2], dw[2], lu[2], ll[2], nu[2], nl[2]; Dyn d; RollIn r; };
-        const bool upd = pend && run;
-        const bool any_upd = __any(upd);
+    // barrier weights of one stage from the iterate
+    auto weights = [&](const Slack &k, int t, const double (&lu)[2], const double (&ll)[2], const double (&nup)[2],
+                       const double (&nlp)[2], double (&wr)[2], double (&we)[2]) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            wr[c] = 2.0 * p.rw[c] + fma(lu[c], k.isu[c], ll[c] * k.isl[c]);
+            we[c] = t > 0 ? 2.0 * p.rdw[c] + fma(nup[c], k.iru[c], nlp[c] * k.irl[c]) : 0.0;
+        }
+    };
+    // rollout at the iterate we start from (the rounds leave their own trial point's behind)
+    if (__any(run)) {
+        struct Rec { double w[2]; Dyn d; RollIn r; };
         Roller ro;
         ro.start(p);
-        double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0}, dapv[2] = {0.0, 0.0};
         sweep<Rec>(0, T - 1, 1,
                    [&](int t, Rec &in) {
-#pragma unroll
-                       for (int c = 0; c < 2; ++c) {
-                           in.w[c] = s.ld(s.p(s.fW, t, c));
-                           if (any_upd) {
-                               in.da[c] = s.ld(s.p(s.fDwa, t, c)); in.dw[c] = s.ld(s.p(s.fDw, t, c));
-                               in.lu[c] = s.ld(s.p(s.fLU, t, c)); in.ll[c] = s.ld(s.p(s.fLL, t, c));
-                               in.nu[c] = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0;
-                               in.nl[c] = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
-                           }
-                       }
-                       if (do_roll) { load_dyn(s, t, in.d); load_roll(s, t, in.r); }
+                       in.w[0] = s.ld(s.p(s.fW, t, 0)); in.w[1] = s.ld(s.p(s.fW, t, 1));
+                       load_dyn(s, t, in.d);
+                       load_roll(s, t, in.r);
                    },
-                   [&](int t, const Rec &in) {
-                       double wnew[2] = {in.w[0], in.w[1]};
-                       if (any_upd) {   // old controls of the previous stage are kept for the rate terms
-                           Slack k;
-                           slacks(p, t, in.w, wpv, k);
-#pragma unroll
-                           for (int c = 0; c < 2; ++c) {
-                               const double da = in.da[c], dw = in.dw[c], lu = in.lu[c], ll = in.ll[c], nu = in.nu[c], nl = in.nl[c];
-                               double qu, ql, pu, pl;
-                               corr(k, t, c, lu, ll, nu, nl, da, dapv[c], qu, ql, pu, pl);
-                               const double dvv = dw - dpv[c];
-                               const double zu = dw * k.isu[c], zl = -dw * k.isl[c], vu = dvv * k.iru[c], vl = -dvv * k.irl[c];
-                               wnew[c] = upd ? fma(ap, dw, in.w[c]) : in.w[c];
-                               if (upd) {
-                                   s.st(s.p(s.fW, t, c), wnew[c]);
-                                   s.st(s.p(s.fLU, t, c), fma(ad, fma(lu, zu, qu - lu), lu));
-                                   s.st(s.p(s.fLL, t, c), fma(ad, fma(ll, zl, ql - ll), ll));
-                                   if (t > 0) {
-                                       s.st(s.p(s.fNU, t - 1, c), fma(ad, fma(nu, vu, pu - nu), nu));
-                                       s.st(s.p(s.fNL, t - 1, c), fma(ad, fma(nl, vl, pl - nl), nl));
-                                   }
-                               }
-                               wpv[c] = in.w[c];
-                               dpv[c] = dw;
-                               dapv[c] = da;
-                           }
-                       }
-                       if (do_roll) ro.step(s, p, t, wnew[0], wnew[1], in.d, in.r);
-                   });
-        pend = false;
-    };
+                   [&](int t, const Rec &in) { ro.step(s, p, t, in.w[0], in.w[1], in.d, in.r); });
+    }
     for (int it = 0;; ++it) {
         if (!__any(run)) break;
-        update_and_roll(true);
-        // backward: gradient, residuals, Riccati gains, feed-forward of the predictor (r = -hw)
+        // backward: the pending step, then gradient, residuals, Riccati gains and the feed-forward
+        // of the predictor (r = -hw) at the new iterate
         double musum = 0.0, rdmax = 0.0, scl = 0.0;
         {
-            struct Rec { Dyn d; double wp[2], nup[2], nlp[2], qe[3], lu[2], ll[2], g[2]; };
+            struct Rec { Dyn d; double wp[2], dwp[2], dap[2], nup[2], nlp[2], lu[2], ll[2], qe[3], dq[3], g[2]; };
+            const bool upd = pend && run;
+            const bool any_upd = __any(upd);
             Riccati R;
             R.terminal(p.qf);
             double lam[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0;
             double wn[2] = {0.0, 0.0}, dnun[2] = {0.0, 0.0};   // controls of stage t + 1, nuU - nuL of constraint (t, t + 1)
             double qg = 1.0;
             for (int t = 1; t < T; ++t) qg *= p.growth;        // growth^(T - 1)
-            double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
+            // stage t's controls before and after the pending step, and its steps
+            double wo[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))}, wc[2], dwc[2] = {0.0, 0.0}, dac[2] = {0.0, 0.0};
+            if (any_upd) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) { dwc[c] = s.ld(s.p(s.fDw, T - 1, c)); dac[c] = s.ld(s.p(s.fDwa, T - 1, c)); }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) wc[c] = upd ? fma(ap, dwc[c], wo[c]) : wo[c];
             sweep<Rec>(T - 1, 0, -1,
                        [&](int t, Rec &in) {
                            load_dyn(s, t, in.d);
@@ -564,33 +540,74 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                                in.nlp[c] = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
                                in.lu[c] = s.ld(s.p(s.fLU, t, c)); in.ll[c] = s.ld(s.p(s.fLL, t, c));
                                in.g[c] = s.ld(s.p(s.fG, t, c));
+                               in.dwp[c] = any_upd && t > 0 ? s.ld(s.p(s.fDw, t - 1, c)) : 0.0;
+                               in.dap[c] = any_upd && t > 0 ? s.ld(s.p(s.fDwa, t - 1, c)) : 0.0;
                            }
                            load_qe(s, t, in.qe);
+                           if (any_upd) {
+#pragma unroll
+                               for (int r = 0; r < 3; ++r) in.dq[r] = s.ld(s.f(s.fDq + r, t));
+                           }
                        },
                        [&](int t, const Rec &in) {
                            const Dyn &d = in.d;
-                           const double (&wp)[2] = in.wp, (&nup)[2] = in.nup, (&nlp)[2] = in.nlp;
+                           double wp[2] = {in.wp[0], in.wp[1]}, nup[2] = {in.nup[0], in.nup[1]}, nlp[2] = {in.nlp[0], in.nlp[1]};
+                           double lu[2] = {in.lu[0], in.lu[1]}, ll[2] = {in.ll[0], in.ll[1]};
+                           double qe[3] = {in.qe[0], in.qe[1], in.qe[2]};
+                           if (any_upd) {
+                               Slack ko;   // at the iterate the step was computed for
+                               slacks(p, t, wo, in.wp, ko);
+#pragma unroll
+                               for (int c = 0; c < 2; ++c) {
+                                   double qu, ql, pu, pl;
+                                   corr(ko, t, c, in.lu[c], in.ll[c], in.nup[c], in.nlp[c], dac[c], in.dap[c], qu, ql, pu, pl);
+                                   const double dw = dwc[c], dvv = dw - in.dwp[c];
+                                   const double zu = dw * ko.isu[c], zl = -dw * ko.isl[c], vu = dvv * ko.iru[c], vl = -dvv * ko.irl[c];
+                                   if (upd) {
+                                       lu[c] = fma(ad, fma(in.lu[c], zu, qu - in.lu[c]), in.lu[c]);
+                                       ll[c] = fma(ad, fma(in.ll[c], zl, ql - in.ll[c]), in.ll[c]);
+                                       s.st(s.p(s.fW, t, c), wc[c]);
+                                       s.st(s.p(s.fLU, t, c), lu[c]);
+                                       s.st(s.p(s.fLL, t, c), ll[c]);
+                                       if (t > 0) {
+                                           wp[c] = fma(ap, in.dwp[c], in.wp[c]);
+                                           nup[c] = fma(ad, fma(in.nup[c], vu, pu - in.nup[c]), in.nup[c]);
+                                           nlp[c] = fma(ad, fma(in.nlp[c], vl, pl - in.nlp[c]), in.nlp[c]);
+                                           s.st(s.p(s.fNU, t - 1, c), nup[c]);
+                                           s.st(s.p(s.fNL, t - 1, c), nlp[c]);
+                                       }
+                                   }
+                               }
+                               if (upd) {
+#pragma unroll
+                                   for (int r = 0; r < 3; ++r) {
+                                       qe[r] = fma(ap, in.dq[r], qe[r]);
+                                       s.st(s.f(s.fQe + r, t), qe[r]);
+                                   }
+                               }
+                           }
                            Slack k;
                            slacks(p, t, wc, wp, k);
-                           adjoint_step(in.qe, a02n, a12n, lam);
+                           adjoint_step(qe, a02n, a12n, lam);
                            double wr[2], we[2], wq[3], r[2];
+                           weights(k, t, lu, ll, nup, nlp, wr, we);
 #pragma unroll
                            for (int c = 0; c < 2; ++c) {
-                               const double lu = in.lu[c], ll = in.ll[c];
                                const double hw = input_cost_grad(p, c, t, T, wp[c], wc[c], wn[c])
                                                  + fma(d.b[0][c], lam[0], fma(d.b[1][c], lam[1], d.b[2][c] * lam[2]));
-                               const double ctl = (lu - ll) + (nup[c] - nlp[c]) - dnun[c];
-                               if (p.hb(t, c)) musum = fma(k.su[c], lu, fma(k.sl[c], ll, musum));
+                               const double ctl = (lu[c] - ll[c]) + (nup[c] - nlp[c]) - dnun[c];
+                               if (p.hb(t, c)) musum = fma(k.su[c], lu[c], fma(k.sl[c], ll[c], musum));
                                if (p.hr(c) && t > 0) musum = fma(k.ru[c], nup[c], fma(k.rl[c], nlp[c], musum));
                                rdmax = dmax(rdmax, fabs(hw + ctl));
                                const double g = in.g[c];
                                scl = dmax(scl, dmax(fabs(hw - g), dmax(fabs(g), fabs(ctl))));
-                               wr[c] = 2.0 * p.rw[c] + fma(lu, k.isu[c], ll * k.isl[c]);
-                               we[c] = t > 0 ? 2.0 * p.rdw[c] + fma(nup[c], k.iru[c], nlp[c] * k.irl[c]) : 0.0;
                                r[c] = -hw;
                                dnun[c] = nup[c] - nlp[c];
                                wn[c] = wc[c];
                                wc[c] = wp[c];
+                               wo[c] = in.wp[c];
+                               dwc[c] = in.dwp[c];
+                               dac[c] = in.dap[c];
                            }
                            stage_weight(p, t, qg, wq);
                            Gains gn;
@@ -599,6 +616,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                            a02n = d.a02; a12n = d.a12;
                            qg = qg / p.growth;
                        });
+            pend = false;
         }
         const double mu = musum * inv_m;
         const double scale = dmax(1.0, scl) + 1.0;
@@ -623,7 +641,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
             struct X { double w[2]; };
             double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0};
             forward<X>(s, [&](int t, X &x) { x.w[0] = s.ld(s.p(s.fW, t, 0)); x.w[1] = s.ld(s.p(s.fW, t, 1)); },
-                       [&](int t, const double (&u)[2], const Dyn &, const X &x) {
+                       [&](int t, const double (&u)[2], const double (&)[3], const Dyn &, const X &x) {
                 Slack k;
                 slacks(p, t, x.w, wpv, k);
 #pragma unroll
@@ -642,12 +660,15 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
         const double apa = rp > 1.0 ? rcp_nr(rp) : 1.0, ada = rcp_nr(rdm);
         const double back = 1.0 - dmin(apa, ada);
         if (run) sm = back * back * back * mu;
-        // backward: feed-forward of the corrector, r_t = -(C' q)_t
+        // backward: feed-forward of the corrector, r_t = -(C' q)_t; the gains are formed again from
+        // the iterate (arithmetic the memory system does not see) rather than read back
         {
-            struct Rec { Dyn d; double wp[2], dp[2], nup[2], nlp[2], lu[2], ll[2]; Gains g; };
+            struct Rec { Dyn d; double wp[2], dp[2], nup[2], nlp[2], lu[2], ll[2]; };
             Riccati R;
             R.terminal(p.qf);
             double trn[2] = {0.0, 0.0};    // (pu - pl) of constraint (t, t + 1)
+            double qg = 1.0;
+            for (int t = 1; t < T; ++t) qg *= p.growth;
             double wc[2] = {s.ld(s.p(s.fW, T - 1, 0)), s.ld(s.p(s.fW, T - 1, 1))};
             double dc[2] = {s.ld(s.p(s.fDwa, T - 1, 0)), s.ld(s.p(s.fDwa, T - 1, 1))};
             sweep<Rec>(T - 1, 0, -1,
@@ -661,12 +682,12 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                                in.nlp[c] = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
                                in.lu[c] = s.ld(s.p(s.fLU, t, c)); in.ll[c] = s.ld(s.p(s.fLL, t, c));
                            }
-                           gains_of(s, t, in.g);
                        },
                        [&](int t, const Rec &in) {
                            Slack k;
                            slacks(p, t, wc, in.wp, k);
-                           double r[2];
+                           double r[2], wr[2], we[2], wq[3];
+                           weights(k, t, in.lu, in.ll, in.nup, in.nlp, wr, we);
 #pragma unroll
                            for (int c = 0; c < 2; ++c) {
                                double qu, ql, pu, pl;
@@ -676,14 +697,21 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                                wc[c] = in.wp[c];
                                dc[c] = in.dp[c];
                            }
-                           riccati_vector_step(s, t, in.d, r, in.g.Lx, in.g.Lv, in.g.Hi, R, run);
+                           stage_weight(p, t, qg, wq);
+                           Gains gn;
+                           riccati_matrix_step(s, t, in.d, wr, we, wq, R, gn, false);
+                           riccati_vector_step(s, t, in.d, r, gn.Lx, gn.Lv, gn.Hi, R, run);
+                           qg = qg / p.growth;
                        });
         }
-        // forward: full step, its step lengths
+        // forward: full step, its step lengths, the change of the rollout along it
         double rp2 = 0.0, rd2 = 0.0, chk = 0.0;
         {
             struct X { double w[2], da[2], lu[2], ll[2], nu[2], nl[2]; };
             double wpv[2] = {0.0, 0.0}, dpv[2] = {0.0, 0.0}, dapv[2] = {0.0, 0.0};
+            // this sweep's own state step belongs to the corrector's difference to the predictor;
+            // the state step of the whole step is rolled beside it
+            double dxf[3] = {0.0, 0.0, 0.0}, qgf = 1.0;
             forward<X>(s,
                        [&](int t, X &x) {
 #pragma unroll
@@ -694,13 +722,15 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                                x.nl[c] = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
                            }
                        },
-                       [&](int t, const double (&uc)[2], const Dyn &, const X &x) {
+                       [&](int t, const double (&uc)[2], const double (&)[3], const Dyn &d, const X &x) {
                 Slack k;
                 slacks(p, t, x.w, wpv, k);
+                double dwv[2];
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const double da = x.da[c];
                     const double dw = da + uc[c];
+                    dwv[c] = dw;
                     if (run) s.st(s.p(s.fDw, t, c), dw);
                     const double lu = x.lu[c], ll = x.ll[c], nu = x.nu[c], nl = x.nl[c];
                     double qu, ql, pu, pl;
@@ -724,6 +754,17 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                     dpv[c] = dw;
                     dapv[c] = da;
                 }
+                const double n0 = dxf[0] + d.a02 * dxf[2] + d.b[0][0] * dwv[0] + d.b[0][1] * dwv[1];
+                const double n1 = dxf[1] + d.a12 * dxf[2] + d.b[1][0] * dwv[0] + d.b[1][1] * dwv[1];
+                const double n2 = dxf[2] + d.b[2][0] * dwv[0] + d.b[2][1] * dwv[1];
+                dxf[0] = n0; dxf[1] = n1; dxf[2] = n2;
+                const int ts = t + 1;
+                if (ts < T) qgf *= p.growth;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double q = ts < T ? p.q[r] * qgf : p.qf[r];
+                    if (run) s.st(s.f(s.fDq + r, t), 2.0 * q * dxf[r]);
+                }
             });
         }
         // a factorisation that broke down leaves NaN in the step: stop at the iterate we have
@@ -739,7 +780,6 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
             pend = true;
         }
     }
-    if (__any(pend && run)) update_and_roll(false);   // whoever continues from here rolls for itself
 }
 
 // ------------------------------------------------------------------------------------
@@ -1109,7 +1149,7 @@ __device__ __forceinline__ void rounds_forward(const Store &s, const Problem &p,
     Roller ro;
     ro.start(p);
     forward<X>(s, [&](int t, X &x) { x.w[0] = s.ld(s.p(s.fW, t, 0)); x.w[1] = s.ld(s.p(s.fW, t, 1)); load_roll(s, t, x.r); },
-               [&](int t, const double (&u)[2], const Dyn &d, const X &x) {
+               [&](int t, const double (&u)[2], const double (&)[3], const Dyn &d, const X &x) {
         double wst[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
