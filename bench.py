@@ -159,7 +159,7 @@ def other_configs(steps: int = 3):
     res = []
     courses = workload.make_courses(64, seed=1001)
     for name, B, T, kernel in (("diff_drive", 262144, None, "k_solve_pair5<diff-drive>"),
-                               ("mpc_py", 65536, None, "k_solve_pair10<dual-steer>"),
+                               ("mpc_py", 65536, None, "k_solve_stage<dual-steer>"),
                                ("dsr_diff", 65536, 30, "k_solve_stage<dual-steer>"),
                                ("dsr_ackermann", 65536, 30, "k_solve_stage<dual-steer>")):
         v = variants.get(name, T=T) if T else variants.get(name)

@@ -1141,7 +1141,7 @@ static int64_t stage_chunk(int64_t B)
     return B < cap ? ((B + kWave - 1) / kWave) * kWave : cap;
 }
 
-// test hook: MPCX_STAGEWISE=1 routes every horizon other than 5 and 10 to the stage-wise kernel,
+// test hook: MPCX_STAGEWISE=1 routes every horizon other than 5 to the stage-wise kernel,
 // =0 every one the wavefront-per-instance kernel can take to that kernel
 static const int g_stagewise = [] { const char *e = getenv("MPCX_STAGEWISE"); return e ? atoi(e) : -1; }();
 
@@ -1158,17 +1158,27 @@ static int64_t wave_batch_max(int T)
 
 enum SolvePath { kPathPair5, kPathReg5, kPathPair10, kPathWave, kPathStage };
 
-// T = 5 with every bound present: lane-pair kernel, chained or not.  T = 10 (mpc.py) with both
-// boxes present, unchained: its T = 10 instantiation.  Other horizons: batches of unchained
-// solves up to T = 32 that the chip holds at once go one wavefront per instance (lower latency:
-// 64 lanes share one instance), everything else one lane per instance with stage-wise linear algebra (far
+// Largest batch the T = 10 lane-pair kernel is given.  The chip holds 16,384 of its instances at
+// once (70 KB of LDS per wavefront: two wavefronts per CU) and every further 16,384 cost the
+// same 0.37 ms again, while the stage-wise kernel streams at 5 TB/s from its first wavefront on:
+// measured on mpc.py's controller, warm, 32,768 instances take 0.76 ms against 0.82 ms, 65,536
+// take 1.47 ms against 1.15 ms.
+constexpr int64_t kPair10BatchMax = 32768;
+
+// T = 5 with every bound present: lane-pair kernel, chained or not.  Other horizons, unchained,
+// up to T = 32: batches that the chip holds at once go one wavefront per instance (lowest
+// latency: 64 lanes share one instance; T = 10: 0.18-0.21 ms against 0.27-0.29 ms for the lane
+// pairs).  T = 10 (mpc.py) with both boxes present: the T = 10 lane-pair kernel up to
+// kPair10BatchMax.  Everything else one lane per instance with stage-wise linear algebra (far
 // higher throughput once the chip is filled).
 static SolvePath choose_path(const mpcx_variant *v, int64_t B, bool chained)
 {
     if (uses_registers(v)) return g_force_single_lane ? kPathReg5 : kPathPair5;
-    if (v->T == 10 && boxes_present(v) && !chained && !g_force_single_lane) return kPathPair10;
     const bool wave_fits = v->T <= 32 && !chained;
-    if (wave_fits && (g_stagewise >= 0 ? g_stagewise == 0 : B <= wave_batch_max(v->T))) return kPathWave;
+    if (g_stagewise == 1) return kPathStage;
+    if (g_stagewise == 0 && wave_fits) return kPathWave;
+    if (wave_fits && B <= wave_batch_max(v->T)) return kPathWave;
+    if (v->T == 10 && boxes_present(v) && !chained && !g_force_single_lane && B <= kPair10BatchMax) return kPathPair10;
     return kPathStage;
 }
 

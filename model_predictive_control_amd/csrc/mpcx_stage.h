@@ -1186,11 +1186,10 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
     const bool ran = run;
     Sets S;
     S.clear();
-    // working set off the iterate (multiplier above slack), backup of the controls, rollout
+    // working set off the iterate (multiplier above slack), backup of the controls; the interior
+    // point leaves the rollout of its last iterate behind
     if (__any(run)) {
-        struct Rec { double w[2], lu[2], ll[2], nu[2], nl[2]; Dyn d; RollIn r; };
-        Roller ro;
-        ro.start(p);
+        struct Rec { double w[2], lu[2], ll[2], nu[2], nl[2]; };
         double wpv[2] = {0.0, 0.0};
         sweep<Rec>(0, T - 1, 1,
                    [&](int t, Rec &in) {
@@ -1201,8 +1200,6 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
                            in.nu[c] = t > 0 ? s.ld(s.p(s.fNU, t - 1, c)) : 0.0;
                            in.nl[c] = t > 0 ? s.ld(s.p(s.fNL, t - 1, c)) : 0.0;
                        }
-                       load_dyn(s, t, in.d);
-                       load_roll(s, t, in.r);
                    },
                    [&](int t, const Rec &in) {
 #pragma unroll
@@ -1220,7 +1217,6 @@ __device__ __forceinline__ bool pdas(const Store &s, const Problem &p, int max_r
                            }
                            wpv[c] = wc;
                        }
-                       ro.step(s, p, t, in.w[0], in.w[1], in.d, in.r);
                    });
     }
     bool accepted = false;

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round validation on the GPU box: GPU tests, smoke, bench, kernel-trace stats, and the counter
-# passes (each in a run of its own) of the headline kernel, the T = 10 kernel and the stage-wise
-# kernel.  Every GPU step has its own time limit and the chain stops at the first failure.
+# passes (each in a run of its own) of the headline kernel, the T = 10 lane-pair kernel (32,768
+# instances, the largest batch routed to it) and the stage-wise kernel (T = 10 and T = 30 at 65,536).
+# Every GPU step has its own time limit and the chain stops at the first failure.
 # Afterwards, here: python scripts/summarise_profiles.py <tag>  (writes profiles/).
 set -o pipefail
 TAG=${1:-r2}
@@ -25,9 +26,12 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 30
  && pmc pmc_write WRITE_SIZE -- bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs \
  && pmc sq5_a $SQ_A -- scripts/prof_solve.py dsr_ackermann 65536 5 \
  && pmc sq5_b $SQ_B -- scripts/prof_solve.py dsr_ackermann 65536 5 \
- && pmc p10_fetch FETCH_SIZE -- scripts/prof_solve.py mpc_py 65536 5 \
- && pmc p10_write WRITE_SIZE -- scripts/prof_solve.py mpc_py 65536 5 \
- && pmc p10_sq $SQ_A -- scripts/prof_solve.py mpc_py 65536 3 \
+ && pmc p10_fetch FETCH_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \
+ && pmc p10_write WRITE_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \
+ && pmc p10_sq $SQ_A -- scripts/prof_solve.py mpc_py 32768 3 \
+ && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s10_trace -o p -- python3 scripts/prof_solve.py mpc_py 65536 5 > $OUT/s10_trace.log 2>&1 \
+ && pmc s10_fetch FETCH_SIZE -- scripts/prof_solve.py mpc_py 65536 5 \
+ && pmc s10_write WRITE_SIZE -- scripts/prof_solve.py mpc_py 65536 5 \
  && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_trace -o p -- python3 scripts/prof_solve.py dsr_ackermann 65536 5 30 > $OUT/st_trace.log 2>&1 \
  && pmc st_fetch FETCH_SIZE -- scripts/prof_solve.py dsr_ackermann 65536 5 30 \
  && pmc st_write WRITE_SIZE -- scripts/prof_solve.py dsr_ackermann 65536 5 30 \

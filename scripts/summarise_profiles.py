@@ -101,10 +101,20 @@ if pw:
 t = traffic("p10_fetch", "p10_write", "k_solve_pair10")
 pw = sq(["p10_sq"], "k_solve_pair10")
 if t or pw:
-    rec = {"kernel": "k_solve_pair10<dual-steer>", "variant": "mpc_py", "T": 10, "batch": 65536, "csrc_sha": sha,
-           "algorithmic_bytes": 65536 * 1209, "traffic": t, "per_wave": pw, "how": how}
+    rec = {"kernel": "k_solve_pair10<dual-steer>", "variant": "mpc_py", "T": 10, "batch": 32768, "csrc_sha": sha,
+           "algorithmic_bytes": 32768 * 1209, "traffic": t, "per_wave": pw, "how": how}
     json.dump(rec, open(os.path.join(PROF, f"{rnd}_pair10_counters.json"), "w"), indent=1)
-    print("pair10 traffic", t and t["bytes_per_launch"], "algorithmic", 65536 * 1209)
+    print("pair10 traffic", t and t["bytes_per_launch"], "algorithmic", 32768 * 1209)
+# stage-wise kernel, T = 10 (mpc.py's controller at the benchmark's batch)
+st = kernel_stats("s10_trace", "p", f"{rnd}_stage_T10_kernel_stats.csv")
+t = traffic("s10_fetch", "s10_write", "k_solve_stage")
+if t:
+    ns, calls = avg_ns(st, "k_solve_stage")
+    rec = {"kernel": "k_solve_stage<dual steer>", "variant": "mpc_py", "T": 10, "batch": 65536, "csrc_sha": sha,
+           "avg_ns": ns, "launches": calls, "hbm_read_bytes": t["fetch_bytes"], "hbm_write_bytes": t["write_bytes"],
+           "hbm_GBps": (t["bytes_per_launch"]) / ns if ns else None, "algorithmic_bytes": 65536 * 1209, "how": how}
+    json.dump(rec, open(os.path.join(PROF, f"{rnd}_stage_T10_traffic.json"), "w"), indent=1)
+    print("stage T10", rec["avg_ns"], "ns", t["bytes_per_launch"] / 1e9, "GB per launch")
 # stage-wise kernel, T = 30
 st = kernel_stats("st_trace", "p", f"{rnd}_stage_T30_kernel_stats.csv")
 kernel_stats("sd_trace", "p", f"{rnd}_stage_T30_dsr_diff_kernel_stats.csv")

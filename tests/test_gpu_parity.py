@@ -226,11 +226,13 @@ def test_infeasible_nonfinite_and_tiny_batches(eng):
     assert out["u"].shape[0] == 0
 
 
-def test_mpc_py_horizon_10_lane_pair_kernel(eng):
+@pytest.mark.parametrize("B", [2048 + 21, 4096 + 21, 32768 + 85])
+def test_mpc_py_horizon_10(eng, B):
     """mpc.py's controller (T = 10, dt = 0.1, input-difference cost, no rate bound on the
-    speeds) runs on the T = 10 instantiation of the lane-pair kernel: ragged batch, warm/cold
-    mix, non-finite and infeasible instances, tiny batches, and the one-QP entry point."""
-    B = 2048 + 21
+    speeds) on each kernel its batch size routes it to (a wavefront per instance up to 3,072,
+    the T = 10 instantiation of the lane-pair kernel up to 32,768, stage-wise beyond): ragged
+    batch, warm/cold mix, non-finite and infeasible instances, tiny batches, and the one-QP
+    entry point."""
     v, ov, x0, xref = make_problem("mpc_py", B, seed=13)
     ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
     out = eng.solve_batch(v, x0, xref)
