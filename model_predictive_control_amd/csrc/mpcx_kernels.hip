@@ -546,12 +546,24 @@ __global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs
     const double *__restrict__ xr = a.xref + b * 3 * W;
     p.x0[0] = a.x0[b * 3]; p.x0[1] = a.x0[b * 3 + 1]; p.x0[2] = a.x0[b * 3 + 2];
     bool finite = finite_d(p.x0[0]) && finite_d(p.x0[1]) && finite_d(p.x0[2]);
-    for (int r = 0; r < 3; ++r)
-        for (int ts = 0; ts < W; ++ts) {
-            const double x = xr[r * W + ts];
-            finite = finite && finite_d(x);
-            if (ts > 0) s.st(s.f(s.fXr + r, ts - 1), x);
-        }
+    // The instance's inputs are requested eight stages at a time: a load issued after a store
+    // waits behind it, so element-by-element copying would cost one memory round trip each.
+    constexpr int kChunk = 8;
+    for (int t0 = 0; t0 < W; t0 += kChunk) {
+        double x[3][kChunk];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) x[r][k] = xr[r * W + (t0 + k < W ? t0 + k : W - 1)];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) {
+                const int ts = t0 + k;
+                finite = finite && finite_d(x[r][k]);   // past the end: the last column again
+                if (ts > 0 && ts < W) s.st(s.f(s.fXr + r, ts - 1), x[r][k]);
+            }
+    }
     const double *uin = a.uin ? a.uin + b * NU * T : nullptr;
     const bool warm = a.linear_mode || (uin && (!a.has_prev || a.has_prev[b]));
     const int chain = a.linear_mode ? 1 : (v.chain > 1 ? (v.chain < T ? v.chain : T) : 1);
@@ -560,24 +572,37 @@ __global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs
     // of the controls, the rest zero (mpc_sim.py:292-299)
     {
         double th = p.x0[2];
-        for (int t = 0; t < T; ++t) {
-            double u[4] = {0.0, 0.0, 0.0, 0.0};
+        const double *xb = a.linear_mode ? a.xbar + b * 3 * W : nullptr;
+        for (int t0 = 0; t0 < T; t0 += kChunk) {
+            double uu[4][kChunk], xs[3][kChunk];
 #pragma unroll
-            for (int r = 0; r < NU; ++r) {
-                u[r] = warm ? uin[r * T + t] : v.cold_start[r];
-                finite = finite && finite_d(u[r]);
-            }
-            if (a.linear_mode) {
-                th = a.xbar[b * 3 * W + 2 * W + t];
-                for (int r = 0; r < 3; ++r) finite = finite && finite_d(a.xbar[b * 3 * W + r * W + t]);
-            }
-            s.st(s.f(s.fTheta, t), th);
-            th = th + yaw_rate<MODEL>(v, u) * v.dt;
+            for (int k = 0; k < kChunk; ++k) {
+                const int tt = t0 + k < T ? t0 + k : T - 1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s.st(s.f(s.fUref + r, t), (chain > 1 && t > 0) ? 0.0 : u[r]);
+                for (int r = 0; r < 4; ++r) uu[r][k] = r < NU ? (warm ? uin[r * T + tt] : v.cold_start[r]) : 0.0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) xs[r][k] = xb ? xb[r * W + tt] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) {
+                const int t = t0 + k;
+                if (t < T) {
+                    double u[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { u[r] = uu[r][k]; finite = finite && finite_d(u[r]); }
+                    if (xb) {
+                        th = xs[2][k];
+                        finite = finite && finite_d(xs[0][k]) && finite_d(xs[1][k]) && finite_d(xs[2][k]);
+                    }
+                    s.st(s.f(s.fTheta, t), th);
+                    th = th + yaw_rate<MODEL>(v, u) * v.dt;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s.st(s.f(s.fUref + r, t), (chain > 1 && t > 0) ? 0.0 : u[r]);
+                }
+            }
         }
-        if (a.linear_mode)
-            for (int r = 0; r < 3; ++r) finite = finite && finite_d(a.xbar[b * 3 * W + r * W + T]);
+        if (xb)
+            for (int r = 0; r < 3; ++r) finite = finite && finite_d(xb[r * W + T]);
     }
     int status = MPCX_ST_OK, iters = 0;
     bool skip = !finite;
@@ -597,12 +622,12 @@ __global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs
     for (int r = 0; r < 3; ++r) { p.q[r] = v.Q[r]; p.qf[r] = v.Qf[r]; }
     p.growth = v.q_growth;
     const double sg = v.eq_mode == MPCX_EQ_ACKERMANN ? -1.0 : 1.0;
-    auto controls = [&](int t, double (&u)[4]) {
-        const double w0 = s.ld(s.p(s.fW, t, 0)), w1 = s.ld(s.p(s.fW, t, 1));
+    auto controls_of = [&](double w0, double w1, double (&u)[4]) {
         if (v.eq_mode == MPCX_EQ_NONE) { u[0] = w0; u[1] = w1; u[2] = 0.0; u[3] = 0.0; }
         else if (v.eq_mode == MPCX_EQ_FIXED_STEER) { u[0] = w0; u[1] = v.steer_fixed; u[2] = w1; u[3] = v.steer_fixed; }
         else { u[0] = w0; u[1] = w1; u[2] = w0; u[3] = sg * w1; }
     };
+    auto controls = [&](int t, double (&u)[4]) { controls_of(s.ld(s.p(s.fW, t, 0)), s.ld(s.p(s.fW, t, 1)), u); };
     for (int t = 0; t < T; ++t) { s.st(s.p(s.fW, t, 0), 0.0); s.st(s.p(s.fW, t, 1), 0.0); }
 
     bool inaccurate = false;
@@ -613,23 +638,47 @@ __global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs
 #pragma unroll
             for (int r = 0; r < 4; ++r) s.st(s.f(s.fUref + r, pass), u[r]);
         }
-        // stage dynamics at the linearisation point
-        double u0[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int t = 0; t < T; ++t) {
-            double u[4];
+        // Stage dynamics at the linearisation point and, in the same sweep, the two rollouts the
+        // solve starts from: at w = 0 (for the gradient that scales the residual tests) and at the
+        // interior point's starting controls, which the bounds of stage 0 determine.
+        {
+            struct Rec { double u[4], th, xr[3]; };
+            stagewise::Roller at_zero, at_start;
+            at_zero.start(p);
+            at_start.start(p);
+            double wst[2] = {0.0, 0.0};
+            stagewise::sweep<Rec>(0, T - 1, 1,
+                                  [&](int t, Rec &in) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) u[r] = s.ld(s.f(s.fUref + r, t));
-            if (t == 0) { u0[0] = u[0]; u0[1] = u[1]; u0[2] = u[2]; u0[3] = u[3]; }
-            double a02, a12, Bm[3][4], C[3], bt[3][2], ct[3], omega;
-            linearize<MODEL>(v, s.ld(s.f(s.fTheta, t)), u, a02, a12, Bm, C, omega);
-            reduce_controls(v, Bm, C, bt, ct);
-            s.dyn_st(0, t, a02); s.dyn_st(1, t, a12);
+                                      for (int r = 0; r < 4; ++r) in.u[r] = s.ld(s.f(s.fUref + r, t));
+                                      in.th = s.ld(s.f(s.fTheta, t));
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { s.dyn_st(2 + 2 * r, t, bt[r][0]); s.dyn_st(3 + 2 * r, t, bt[r][1]); s.dyn_st(8 + r, t, ct[r]); }
+                                      for (int r = 0; r < 3; ++r) in.xr[r] = s.ld(s.f(s.fXr + r, t));
+                                  },
+                                  [&](int t, const Rec &in) {
+                                      if (t == 0) {
+                                          free_bounds(v, in.u, p.fb);
+                                          wst[0] = p.start(0); wst[1] = p.start(1);
+                                      }
+                                      double a02, a12, Bm[3][4], C[3], bt[3][2], ct[3], omega;
+                                      linearize<MODEL>(v, in.th, in.u, a02, a12, Bm, C, omega);
+                                      reduce_controls(v, Bm, C, bt, ct);
+                                      stagewise::Dyn d;
+                                      stagewise::RollIn ri;
+                                      d.a02 = a02; d.a12 = a12;
+                                      s.dyn_st(0, t, a02); s.dyn_st(1, t, a12);
+#pragma unroll
+                                      for (int r = 0; r < 3; ++r) {
+                                          d.b[r][0] = bt[r][0]; d.b[r][1] = bt[r][1];
+                                          ri.c[r] = ct[r]; ri.xr[r] = in.xr[r];
+                                          s.dyn_st(2 + 2 * r, t, bt[r][0]); s.dyn_st(3 + 2 * r, t, bt[r][1]); s.dyn_st(8 + r, t, ct[r]);
+                                      }
+                                      at_zero.step(s, p, t, 0.0, 0.0, d, ri, s.fDq);
+                                      at_start.step(s, p, t, wst[0], wst[1], d, ri);
+                                  });
         }
-        free_bounds(v, u0, p.fb);
         if (!p.fb.feasible && !skip) { skip = true; status = MPCX_ST_INFEASIBLE; }
-        const double gmax = stagewise::gradient_at_zero(s, p);
+        const double gmax = stagewise::gradient_at_zero(s, s.fDq);
         // initial complementarity in proportion to the gradient: with weights that grow like 2^t
         // (mpc_dsr.py:349) the gradient reaches 1e7, and from 0.1 the interior point spends 25
         // iterations just raising its multipliers to that scale
@@ -647,7 +696,7 @@ __global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs
             if (!__any(todo)) break;
             int it = 0, used = 0;
             const int cap = a.max_iter < kStageIpmCap || attempt + 1 == kStageAttempts ? a.max_iter : kStageIpmCap;
-            stagewise::ipm(s, p, cap, kStageSwitchMu[attempt], attempt > 0, todo, st, it);
+            stagewise::ipm(s, p, cap, kStageSwitchMu[attempt], attempt > 0, todo, st, it, /*rolled=*/true);
             if (todo) { iters += it; spent += it; status = st; }
             const bool ok = stagewise::pdas(s, p, kStageRounds[attempt], todo, used);
 #ifdef MPCX_DIAG   // diagnostic builds report the rounds in the iteration count
@@ -675,32 +724,40 @@ __global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs
 #pragma unroll
         for (int r = 0; r < 3; ++r) xo[r * W] = bad ? nan : x[r];
     }
-    for (int t = 0; t < T; ++t) {
-        double u[4];
-        controls(t, u);
-        const double w0 = s.ld(s.p(s.fW, t, 0)), w1 = s.ld(s.p(s.fW, t, 1));
+    {
+        struct Rec { double w[2]; stagewise::Dyn d; stagewise::RollIn r; };
+        stagewise::sweep<Rec>(0, T - 1, 1,
+                              [&](int t, Rec &in) {
+                                  in.w[0] = s.ld(s.p(s.fW, t, 0)); in.w[1] = s.ld(s.p(s.fW, t, 1));
+                                  stagewise::load_dyn(s, t, in.d);
+                                  stagewise::load_roll(s, t, in.r);
+                              },
+                              [&](int t, const Rec &in) {
+            const double w0 = in.w[0], w1 = in.w[1];
+            double u[4];
+            controls_of(w0, w1, u);
 #pragma unroll
-        for (int r = 0; r < NU; ++r) {
-            J = fma(v.R[r] * u[r], u[r], J);
-            if (t > 0) { const double d = u[r] - up[r]; J = fma(v.Rd[r] * d, d, J); }
-            up[r] = u[r];
-            if (live) uo[r * T + t] = bad ? nan : u[r];
-        }
-        stagewise::Dyn d;
-        stagewise::load_dyn(s, t, d);
-        const double n0 = x[0] + d.a02 * x[2] + d.b[0][0] * w0 + d.b[0][1] * w1 + s.dyn(8, t);
-        const double n1 = x[1] + d.a12 * x[2] + d.b[1][0] * w0 + d.b[1][1] * w1 + s.dyn(9, t);
-        const double n2 = x[2] + d.b[2][0] * w0 + d.b[2][1] * w1 + s.dyn(10, t);
-        x[0] = n0; x[1] = n1; x[2] = n2;
-        const int ts = t + 1;
-        if (ts < T) qg *= v.q_growth;
+            for (int r = 0; r < NU; ++r) {
+                J = fma(v.R[r] * u[r], u[r], J);
+                if (t > 0) { const double d = u[r] - up[r]; J = fma(v.Rd[r] * d, d, J); }
+                up[r] = u[r];
+                if (live) uo[r * T + t] = bad ? nan : u[r];
+            }
+            const stagewise::Dyn &d = in.d;
+            const double n0 = x[0] + d.a02 * x[2] + d.b[0][0] * w0 + d.b[0][1] * w1 + in.r.c[0];
+            const double n1 = x[1] + d.a12 * x[2] + d.b[1][0] * w0 + d.b[1][1] * w1 + in.r.c[1];
+            const double n2 = x[2] + d.b[2][0] * w0 + d.b[2][1] * w1 + in.r.c[2];
+            x[0] = n0; x[1] = n1; x[2] = n2;
+            const int ts = t + 1;
+            if (ts < T) qg *= v.q_growth;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double e = xr[r * W + ts] - x[r];
-            const double q = ts < T ? v.Q[r] * qg : v.Qf[r];
-            J = fma(q * e, e, J);
-            if (live) xo[r * W + ts] = bad ? nan : x[r];
-        }
+            for (int r = 0; r < 3; ++r) {
+                const double e = in.r.xr[r] - x[r];   // the workspace's copy of the reference window
+                const double q = ts < T ? v.Q[r] * qg : v.Qf[r];
+                J = fma(q * e, e, J);
+                if (live) xo[r * W + ts] = bad ? nan : x[r];
+            }
+        });
     }
     if (live) {
         a.obj_out[b] = bad ? nan : J;

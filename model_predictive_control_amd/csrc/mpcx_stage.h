@@ -93,6 +93,8 @@ struct Problem {
     __device__ __forceinline__ double lo(int t, int c) const { return t == 0 ? fb.lo0[c] : -fb.b[c]; }
     __device__ __forceinline__ double hi(int t, int c) const { return t == 0 ? fb.hi0[c] : fb.b[c]; }
     __device__ __forceinline__ bool hr(int c) const { return fb.rate[c]; }
+    // where the interior point starts: every stage at the middle of its channel's first-stage window
+    __device__ __forceinline__ double start(int c) const { return hb(0, c) ? 0.5 * (lo(0, c) + hi(0, c)) : 0.0; }
 };
 
 struct Dyn {
@@ -156,7 +158,7 @@ struct Roller {
     double x[3], qg;
     __device__ __forceinline__ void start(const Problem &p) { x[0] = p.x0[0]; x[1] = p.x0[1]; x[2] = p.x0[2]; qg = 1.0; }
     __device__ __forceinline__ void step(const Store &s, const Problem &p, int t, double w0, double w1, const Dyn &d,
-                                         const RollIn &in)
+                                         const RollIn &in, int dst = Store::fQe)
     {
         const int T = s.T;
         const double n0 = x[0] + d.a02 * x[2] + d.b[0][0] * w0 + d.b[0][1] * w1 + in.c[0];
@@ -168,19 +170,10 @@ struct Roller {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double q = ts < T ? p.q[r] * qg : p.qf[r];
-            s.st(s.f(s.fQe + r, t), 2.0 * q * (x[r] - in.xr[r]));
+            s.st(s.f(dst + r, t), 2.0 * q * (x[r] - in.xr[r]));
         }
     }
 };
-__device__ __forceinline__ void roll_zero(const Store &s, const Problem &p)
-{
-    struct Rec { Dyn d; RollIn r; };
-    Roller ro;
-    ro.start(p);
-    sweep<Rec>(0, s.T - 1, 1, [&](int t, Rec &in) { load_dyn(s, t, in.d); load_roll(s, t, in.r); },
-               [&](int t, const Rec &in) { ro.step(s, p, t, 0.0, 0.0, in.d, in.r); });
-}
-
 // The backward sweeps of the interior point and of the active-set rounds have one shape: from
 // the last stage to the first they form hw_t = (H w + g)_t (adjoint of the rollout + the input
 // cost terms), the right-hand side r_t of the phase, the Riccati gains of
@@ -369,14 +362,19 @@ __device__ __forceinline__ void load_qe(const Store &s, int t, double (&qe)[3])
     for (int r = 0; r < 3; ++r) qe[r] = s.ld(s.f(s.fQe + r, t));
 }
 
-// Gradient at w = 0 (the g of the condensed problem), kept for the scale of the residual tests.
-__device__ __forceinline__ double gradient_at_zero(const Store &s, const Problem &p)
+// Gradient at w = 0 (the g of the condensed problem), kept for the scale of the residual tests:
+// the adjoint sweep over the rollout at w = 0 that the caller left in field `qe0`.
+__device__ __forceinline__ double gradient_at_zero(const Store &s, int qe0)
 {
     struct Rec { Dyn d; double qe[3]; };
     double gmax = 0.0;
-    roll_zero(s, p);
     double lam[3] = {0.0, 0.0, 0.0}, a02n = 0.0, a12n = 0.0;
-    sweep<Rec>(s.T - 1, 0, -1, [&](int t, Rec &in) { load_dyn(s, t, in.d); load_qe(s, t, in.qe); },
+    sweep<Rec>(s.T - 1, 0, -1,
+               [&](int t, Rec &in) {
+                   load_dyn(s, t, in.d);
+#pragma unroll
+                   for (int r = 0; r < 3; ++r) in.qe[r] = s.ld(s.f(qe0 + r, t));
+               },
                [&](int t, const Rec &in) {
                    const Dyn &d = in.d;
                    adjoint_step(in.qe, a02n, a12n, lam);
@@ -437,9 +435,10 @@ __device__ __forceinline__ void slacks(const Problem &p, int t, const double (&w
 // stops as soon as its complementarity is below mu_stop and its dual residual is small (the
 // active set can then be read off the iterate); otherwise it runs to convergence; at most
 // max_iter iterations either way.  `resume` continues from the stored iterate (controls and
-// multipliers as the previous call left them) instead of starting over.
+// multipliers as the previous call left them) instead of starting over.  `rolled`: the rollout of
+// the starting controls (Problem::start) is already in place.
 __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_iter, double mu_stop, bool resume, bool run,
-                                    int &status, int &iters)
+                                    int &status, int &iters, bool rolled = false)
 {
     const int T = s.T;
     const double inv_m = [&] {
@@ -450,9 +449,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
     }();
     if (run && !resume) {
         // strictly feasible start: every stage at the middle of its channel's first-stage window
-        double wc[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) wc[c] = p.hb(0, c) ? 0.5 * (p.lo(0, c) + p.hi(0, c)) : 0.0;
+        const double wc[2] = {p.start(0), p.start(1)};
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -494,8 +491,9 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
             we[c] = t > 0 ? 2.0 * p.rdw[c] + fma(nup[c], k.iru[c], nlp[c] * k.irl[c]) : 0.0;
         }
     };
-    // rollout at the iterate we start from (the rounds leave their own trial point's behind)
-    if (__any(run)) {
+    // rollout at the iterate we start from (the rounds leave their own trial point's behind);
+    // `rolled`: the caller has already rolled the starting controls
+    if (__any(run) && !(rolled && !resume)) {
         struct Rec { double w[2]; Dyn d; RollIn r; };
         Roller ro;
         ro.start(p);
