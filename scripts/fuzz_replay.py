@@ -1,3 +1,5 @@
+"""Replays seeds of tests/test_gpu_fuzz.py with the comparison printed instead of asserted (statuses,
+worst control difference, certificate of both answers).  python scripts/fuzz_replay.py seed..."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,6 @@
+"""Stress inputs (vehicles far off course, any heading, random previous controls) through the
+stage-wise kernel: instances whose controls differ from the oracle's by more than 1e-5, and the
+solver-independent KKT certificate of both answers.  python scripts/stress_certificate.py name T"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,7 +1,7 @@
 """Per-wavefront view of the stage-wise kernel's work on the benchmark-shaped inputs (diagnostic
 build: MPCX_LIB=.../libmpcx_diag.so): interior-point iterations and rounds per lane, and what the
 slowest lane of each 64-lane wavefront needs, which is what the wavefront pays.
-    python scripts/dbg_waves.py name B T"""
+    python scripts/wave_stats.py name B T"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
