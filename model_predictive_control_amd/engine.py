@@ -269,7 +269,9 @@ class ClosedLoop:
         """Initial yaw compensation against the course's first yaw and the first nearest index
         searched from the course start (mpc_diff_drive.py:336-350)."""
         cid = self.course_id.long() if self.course_id is not None else torch.zeros(self.B, dtype=torch.long, device=self.state.device)
-        d = self.state[:, 2] - self.table.cyaw[cid, 0]
+        # a course id outside the table is an empty window to the kernels; here it must not index
+        ok = (cid >= 0) & (cid < self.table.K)
+        d = torch.where(ok, self.state[:, 2] - self.table.cyaw[cid.clamp(0, self.table.K - 1), 0], torch.zeros_like(self.state[:, 2]))
         two_pi = 2.0 * math.pi
         self.state[:, 2] = torch.where(d >= math.pi, self.state[:, 2] - two_pi,
                                        torch.where(d <= -math.pi, self.state[:, 2] + two_pi, self.state[:, 2]))
@@ -410,7 +412,8 @@ class SegmentedLoop:
         t = self.table
         cid = self.course_id[idx].long()
         yaw = self.state[idx, 2]
-        d = yaw - t.cyaw[cid, 0]
+        ok = (cid >= 0) & (cid < t.K)      # rows outside the table: an empty window, never an index
+        d = torch.where(ok, yaw - t.cyaw[cid.clamp(0, t.K - 1), 0], torch.zeros_like(yaw))
         two_pi = 2.0 * math.pi
         self.state[idx, 2] = torch.where(d >= math.pi, yaw - two_pi, torch.where(d <= -math.pi, yaw + two_pi, yaw))
         st = self.state[idx].contiguous()

@@ -83,6 +83,24 @@ def test_goal_freezes_a_vehicle_and_failure_means_cold_start():
     np.testing.assert_array_equal(loop.state.cpu().numpy()[0], frozen)
 
 
+def test_course_ids_outside_the_table_lose_their_window():
+    """A vehicle whose course id is not a row of the table has an empty search window on every
+    kernel of the tick (where the reference raises): it is marked lost on the first tick and never
+    moves; its neighbours are unaffected."""
+    from model_predictive_control_amd import engine, variants
+    v = variants.get("dsr_ackermann")
+    cx = np.linspace(0.0, 20.0, 201); cy = np.zeros(201); cyaw = np.zeros(201)
+    table = engine.CourseTable([(cx, cy, cyaw)])
+    state = np.array([[0.1, 0.02, 0.0, 0.0]] * 3)
+    loop = engine.ClosedLoop(v, table, state, np.array([0, 5, -2], np.int32)).run(3)
+    torch.cuda.synchronize()
+    done, got = loop.done.cpu().numpy(), loop.state.cpu().numpy()
+    assert done.tolist() == [0, 2, 2]
+    np.testing.assert_array_equal(got[1], state[1])
+    np.testing.assert_array_equal(got[2], state[2])
+    assert got[0, 0] > state[0, 0]
+
+
 def test_graph_replay_equals_eager_ticks():
     """The tick (reference window -> solve -> advance) allocates nothing, so it can be
     recorded as a HIP graph; replaying it must give exactly the eager loop's states."""
