@@ -1047,7 +1047,9 @@ __global__ __launch_bounds__(256) void k_nearest_ref(int mode, int T, double dt,
     if (len < 0 || (int64_t)len > Lmax) len = 0;
     const int pind = pind_in[b];
     const double x = state[4 * b], y = state[4 * b + 1];
-    const int lo = pind < len ? pind : len;
+    // a negative previous index (a window lost earlier) is an empty window too: never a read
+    // in front of the row
+    const int lo = pind < 0 ? 0 : (pind < len ? pind : len);
     const int64_t end = (int64_t)pind + n_search;
     const int hi = end < len ? (int)end : len;
     double best = kBig;
@@ -1099,13 +1101,21 @@ __global__ __launch_bounds__(256) void k_nearest_ref(int mode, int T, double dt,
         for (int i = 0; i < W; ++i) {
             travel += step;
             if (i % kGroup != k) continue;
-            const long dind = (long)rint(travel / param);
-            const long kk = ind + dind < len ? ind + dind : len - 1;
+            // a speed or spacing that is not a number gives a window that is not one either (the
+            // reference's int(round()) raises there); anything else is clamped onto the row
+            const double q = travel / param;
+            if (!(q == q)) {
+                xr[i] = xr[W + i] = xr[2 * W + i] = __builtin_nan("");
+                continue;
+            }
+            const long dind = q >= (double)len ? (long)len : (q <= -(double)len ? -(long)len : (long)rint(q));
+            long kk = ind + dind < len ? ind + dind : len - 1;
+            if (kk < 0) kk = 0;
             xr[i] = tx[kk]; xr[W + i] = ty[kk]; xr[2 * W + i] = tw[kk];
         }
     } else {
-        int cnt = (int)param;
-        if (ind + cnt > len) cnt = len - ind;
+        int cnt = param >= 1.0 ? (param < 2147483647.0 ? (int)param : 2147483647) : 1;   // at least the point itself
+        if ((int64_t)ind + cnt > len) cnt = len - ind;
         for (int i = k; i < W; i += kGroup) {
             const int kk = ind + (i < cnt ? i : cnt - 1);
             xr[i] = tx[kk]; xr[W + i] = ty[kk]; xr[2 * W + i] = tw[kk];

@@ -450,17 +450,27 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
     if (run && !resume) {
         // strictly feasible start: every stage at the middle of its channel's first-stage window
         const double wc[2] = {p.start(0), p.start(1)};
-        for (int t = 0; t < T; ++t)
+        // The complementarity a constraint starts at follows the gradient of its own stage (capped
+        // by the instance's): with stage weights that grow like 2^t the early stages' multipliers
+        // end five orders of magnitude below the late ones', and starting them all at the scale
+        // of the largest costs iterations that only bring them down.
+        double gn[2] = {fabs(s.ld(s.p(s.fG, 0, 0))), fabs(s.ld(s.p(s.fG, 0, 1)))};
+        for (int t = 0; t < T; ++t) {
+            const double gc[2] = {gn[0], gn[1]};
+            if (t + 1 < T) { gn[0] = fabs(s.ld(s.p(s.fG, t + 1, 0))); gn[1] = fabs(s.ld(s.p(s.fG, t + 1, 1))); }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const bool hb = p.hb(t, c), hr = p.hr(c) && t + 1 < T;
+                const double mub = dmin(p.mu0, kMu0 * dmax(1.0, gc[c]));
+                const double mur = dmin(p.mu0, kMu0 * dmax(1.0, dmax(gc[c], gn[c])));
                 s.st(s.p(s.fW, t, c), wc[c]);
-                s.st(s.p(s.fLU, t, c), hb ? p.mu0 * rcp_nr(dmax(p.hi(t, c) - wc[c], kSlackMin)) : 0.0);
-                s.st(s.p(s.fLL, t, c), hb ? p.mu0 * rcp_nr(dmax(wc[c] - p.lo(t, c), kSlackMin)) : 0.0);
-                const double l0 = hr ? p.mu0 * rcp_nr(p.fb.rr[c]) : 0.0;
+                s.st(s.p(s.fLU, t, c), hb ? mub * rcp_nr(dmax(p.hi(t, c) - wc[c], kSlackMin)) : 0.0);
+                s.st(s.p(s.fLL, t, c), hb ? mub * rcp_nr(dmax(wc[c] - p.lo(t, c), kSlackMin)) : 0.0);
+                const double l0 = hr ? mur * rcp_nr(p.fb.rr[c]) : 0.0;
                 s.st(s.p(s.fNU, t, c), l0);
                 s.st(s.p(s.fNL, t, c), l0);
             }
+        }
     }
     status = MPCX_ST_FAILED;
     iters = 0;
