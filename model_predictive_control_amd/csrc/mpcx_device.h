@@ -663,7 +663,9 @@ __device__ __forceinline__ void ipm_solve(S &s, const FreeBounds &fb, int max_it
         scale += 1.0;
         const bool conv = rdmax <= kTolD * scale && mu <= kTolMu;
         if (!done && conv) { done = true; status = MPCX_ST_OK; my_iters = it; }
-        if (!done && (mu < kMuFloor || it >= max_iter)) {
+        // (without any constraint the complementarity is zero by definition, not by rounding:
+        // the iteration is then a plain Newton step)
+        if (!done && ((inv_m > 0.0 && mu < kMuFloor) || it >= max_iter)) {
             // weakly active constraints make the tail converge linearly; once the barrier
             // parameter is at the rounding floor further steps only add noise
             done = true;

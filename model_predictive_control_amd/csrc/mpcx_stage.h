@@ -636,7 +636,7 @@ __device__ __forceinline__ void ipm(const Store &s, const Problem &p, int max_it
                 status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
                 run = false;
             }
-            else if (mu < kMuFloor || it >= max_iter || !finite_d(mu + rdmax)) {
+            else if ((inv_m > 0.0 && mu < kMuFloor) || it >= max_iter || !finite_d(mu + rdmax)) {
                 iters = it;
                 status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
                 run = false;

@@ -293,7 +293,8 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, bool fixed, int &statu
         const double scale = dmax(1.0, wmax(c.act ? dmax(fabs(hw - c.g), dmax(fabs(c.g), fabs(ctl))) : 0.0)) + 1.0;
         const bool conv = rdmax <= kTolD * scale && mu <= kTolMu;
         if (conv) { status = MPCX_ST_OK; iters = it; return; }
-        if (mu < kMuFloor || it >= max_iter || !finite_d(mu + rdmax)) {
+        // no constraint at all: zero complementarity by definition, the iteration is a Newton step
+        if ((c.inv_m > 0.0 && mu < kMuFloor) || it >= max_iter || !finite_d(mu + rdmax)) {
             iters = it;
             status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
             return;

@@ -561,6 +561,20 @@ static int ipm(const qp_t *q, const int *ip, const int *im, int m, double *w, do
     for (int j = 0; j < m; ++j) { s[j] = q->d[j] > 1.0 ? q->d[j] : 1.0; lam[j] = 1.0; }
     int it = 0, ok = 0;
     resid_t r;
+    if (m == 0) {
+        /* nothing to stay inside of: the minimiser is the Newton point (the numpy twin solves
+           H w = -g directly too) */
+        memcpy(K, q->H, sizeof(double) * n * n);
+        ok = cholesky(K, n) == 0 ? 1 : -1;
+        if (ok > 0) {
+            for (int i = 0; i < n; ++i) w[i] = -q->g[i];
+            chol_solve(K, n, w);
+        }
+        r = residuals(q, ip, im, 0, w, s, lam, rd, rp);
+        *conv = ok;
+        if (kkt) *kkt = r.erd;
+        return 1;
+    }
     for (it = 1; it <= 80; ++it) {
         r = residuals(q, ip, im, m, w, s, lam, rd, rp);
         if (r.erd <= tol && r.erp <= tol && r.mu <= 1e-12) { ok = 1; break; }

@@ -287,6 +287,28 @@ def test_mpc_py_horizon_10(eng, B):
     compare(outl, refl)
 
 
+@pytest.mark.parametrize("name,T,B", [("dsr_diff", 1, 64), ("dsr_ackermann", 5, 300), ("diff_drive", 12, 300),
+                                      ("dsr_crab", 12, 3072 + 64), ("dsr_ackermann", 40, 200)])
+def test_no_constraint_at_all(eng, name, T, B):
+    """Every bound infinite: the QP has no inequality, its minimiser is the Newton point, and the
+    solvers' complementarity measure is zero by definition rather than by rounding (they used to
+    stop there with the starting point).  Wavefront-per-instance and stage-wise kernels, cold and
+    warm, against the oracle and the certificate."""
+    inf = float("inf")
+    nu = 2 if name == "diff_drive" else 4
+    v, ov, x0, xref = make_problem(name, B, seed=29, T=T, umax=(inf,) * nu, dumax=(inf,) * nu, first_step=(inf,) * nu)
+    ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
+    assert (ref["status"] == 0).all() and ref["kkt"].max() <= 1e-12
+    out = eng.solve_batch(v, x0, xref)
+    compare(out, ref, problem=dict(ov=ov, x0=x0, xref=xref))
+    assert (out["status"].cpu().numpy() == 0).all()
+    assert np.abs(out["u"].cpu().numpy()).max() > 1e-3          # not the starting point
+    up = ref["u"].copy()
+    ref2 = orc.iterative_batch(ov, x0, xref, up, None, nthreads=8)
+    out2 = eng.solve_batch(v, x0, xref, up)
+    compare(out2, ref2, problem=dict(ov=ov, x0=x0, xref=xref, uref=up))
+
+
 @pytest.mark.parametrize("T,B", [(16, 300), (16, 3072 + 37), (40, 200)])
 def test_long_horizon_kernels_edge_cases(eng, T, B):
     """Horizons other than 5 and 10: batches the chip holds at once (3,072 instances at T = 16) run
