@@ -27,6 +27,8 @@ for seed in map(int, sys.argv[1:]):
         du = np.abs(u - r["u"]).reshape(B, -1).max(axis=1)
         dobj = np.abs(o["obj"].cpu().numpy() - r["obj"]) / np.maximum(1, np.abs(r["obj"]))
         print(" ", label, "status gpu", np.bincount(st, minlength=5).tolist(), "ref", np.bincount(r["status"], minlength=5).tolist(), "du max", np.nanmax(du), "dobj", np.nanmax(dobj), "iters max", o["iters"].cpu().numpy().max())
+        if not np.array_equal(st, r["status"]) or np.nanmax(du) > 1e-6:
+            print("FLAG seed", seed, label, "statuses differ" if not np.array_equal(st, r["status"]) else "", "du", np.nanmax(du))
         if ov.chain <= 1:
             ok = (st <= 1) & (r["status"] <= 1)
             xb = orc.rollout_batch(ov, x0[ok], ur[ok])
@@ -37,3 +39,5 @@ for seed in map(int, sys.argv[1:]):
                 f = 0.5 * np.einsum("bi,bij,bj->b", w, H, w) + np.einsum("bi,bi->b", g, w)
                 k = np.nanargmax(du[ok])
                 print("    ", nm, "cert stat %.2e viol %.2e neg %.2e" % (stat.max(), viol.max(), neg.max()), " at worst-du instance: stat %.2e f %.12e" % (stat[k], f[k]))
+                if max(stat.max(), neg.max()) > 1e-8 or viol.max() > 1e-9:
+                    print("FLAG seed", seed, label, nm, "certificate", stat.max(), viol.max(), neg.max())
