@@ -872,6 +872,7 @@ __global__ __launch_bounds__(kWave) void k_build_courses(int64_t K, int Nmax, co
     __shared__ double w1[kMaxWaypoints], w2[kMaxWaypoints], w3[kMaxWaypoints], w4[kMaxWaypoints];
     __shared__ int s_len;
     const int64_t k = blockIdx.x;
+    if (k >= K) return;   // the whole block: nothing below is reached by part of it
     const int lane = threadIdx.x;
     const int n = nway[k];
     const bool ok = n >= 2 && n <= Nmax && n <= kMaxWaypoints;

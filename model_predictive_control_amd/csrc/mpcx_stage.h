@@ -212,7 +212,6 @@ __device__ __forceinline__ void riccati_matrix_step(const Store &s, int t, const
                                                     const double (&we)[2], const double (&wq)[3], Riccati &R,
                                                     Gains &gn, bool store)
 {
-    const int T = s.T;
     // BP = B' Pxx + Pxu'  (2 x 3)
     double BP[2][3];
 #pragma unroll
@@ -803,7 +802,7 @@ struct Sets {
         for (int c = 0; c < 2; ++c) bu[c] = bl[c] = ru[c] = rl[c] = 0;
     }
 };
-__device__ __forceinline__ bool bit(uint64_t m, int t) { return ((m >> t) & 1ull) != 0; }
+__device__ __forceinline__ bool bit(uint64_t m, int t) { return t < 64 && ((m >> t) & 1ull) != 0; }   // stage T of a T = 64 horizon: no bit
 __device__ __forceinline__ uint64_t one(int t) { return 1ull << t; }
 
 // Stages whose control is determined by the working set alone: on a box, or tied to such a

@@ -309,7 +309,7 @@ def test_no_constraint_at_all(eng, name, T, B):
     compare(out2, ref2, problem=dict(ov=ov, x0=x0, xref=xref, uref=up))
 
 
-@pytest.mark.parametrize("T,B", [(16, 300), (16, 3072 + 37), (40, 200)])
+@pytest.mark.parametrize("T,B", [(16, 300), (16, 3072 + 37), (40, 200), (64, 130)])
 def test_long_horizon_kernels_edge_cases(eng, T, B):
     """Horizons other than 5 and 10: batches the chip holds at once (3,072 instances at T = 16) run
     one wavefront per instance up to T = 32, larger batches and longer horizons one lane per instance with stage-wise linear algebra.
