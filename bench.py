@@ -151,14 +151,15 @@ def cpu_baseline(x0, xref, uprev, has_prev, seconds_target: float = 12.0):
 def other_configs(steps: int = 3):
     """The survey's other single-GPU configurations, timed briefly beside the headline one
     (inputs resident; "warm" = linearised at their own cold optimum, as the reference's loop
-    feeds the previous answer back): 262,144 diff-drive T=5, 65,536 mpc.py T=10, and mpc_dsr.py
+    feeds the previous answer back): 65,536 and 262,144 diff-drive T=5, 65,536 mpc.py T=10, and mpc_dsr.py
     at T=30 both ways: the QP its iterative_linear_mpc_control actually calls (fixed steer, stage
     weights Q 2^t, mpc_dsr.py:193,349) and the ackermann one."""
     import torch
     from model_predictive_control_amd import engine, variants, workload
     res = []
     courses = workload.make_courses(64, seed=1001)
-    for name, B, T, kernel in (("diff_drive", 262144, None, "k_solve_pair5<diff-drive>"),
+    for name, B, T, kernel in (("diff_drive", 65536, None, "k_solve_pair5<diff-drive>"),
+                               ("diff_drive", 262144, None, "k_solve_pair5<diff-drive>"),
                                ("mpc_py", 65536, None, "k_solve_stage<dual-steer>"),
                                ("dsr_diff", 65536, 30, "k_solve_stage<dual-steer>"),
                                ("dsr_ackermann", 65536, 30, "k_solve_stage<dual-steer>")):
