@@ -186,7 +186,31 @@ def other_configs(steps: int = 3):
                         "solved_fraction": float((out["status"] <= 1).float().mean().item()),
                         "failed": int((out["status"] == 4).sum().item()),
                         "algorithmic_GBps": ab * B / dt / 1e9})
+    res.append(closed_loop_tick())
     return res
+
+
+def closed_loop_tick(B: int = BATCH, n: int = 50):
+    """The fused tick (reference window from the course tables on the device -> solve -> state
+    advance and goal test, no host round trip) of a fleet of the headline variant: per vehicle
+    and tick it reads the state (32 B), previous index and course id (8 B), ten course points
+    and the end point (176 B), the warm start (16 NU T B) and writes the controls, states,
+    objective, status, the new index and state."""
+    import torch
+    from model_predictive_control_amd import engine, variants, workload
+    v = variants.get(VARIANT)
+    courses = workload.make_courses(1024, seed=1001)
+    inst = workload.make_instances(courses, B, seed=2003)
+    loop = engine.ClosedLoop(v, engine.CourseTable(courses), inst["state"][:, :4].copy(), inst["course_id"], pind0=inst["pind"])
+    loop.run(5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop.run(n)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    return {"workload": f"closed-loop tick {VARIANT} T={v.T} fleet {B}", "value": B / dt, "unit": "vehicle-ticks/s",
+            "ms_per_step": dt * 1e3, "kernel": "k_nearest_ref + k_solve_pair5 + k_advance",
+            "still_driving": int((loop.done == 0).sum().item()), "failed": int((loop.out["status"] == 4).sum().item())}
 
 
 def mixed_inputs(rank: int, world: int, total: int):
