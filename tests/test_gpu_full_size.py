@@ -98,38 +98,67 @@ def test_65536_dual_steer_horizon_30():
     _check("dsr_ackermann", 65536, 2048, T=30)
 
 
+def _settle_with_the_arbiter(name, T, v, x0, xref, uref, gpu, ref, idx):
+    """For the instances `idx`, where engine and oracle disagree: the minimiser of the reference's
+    own (x, u) programme on the active set either side found, in extended precision
+    (tests/xu_problem.arbiter), accepted once it passes the KKT certificate of the whole
+    programme.  Returns the distance of the engine's and of the oracle's controls from it."""
+    from model_predictive_control_amd import engine
+    from tests import xu_checks, xu_problem as XU
+    from tests.test_gpu_xu_problem import EngineOps
+    ops = EngineOps(v)
+    xbar = ops.rollout(x0[idx], uref[idx])
+    abc = xu_checks.stage_matrices(ops, xbar, uref[idx])
+    d_gpu, d_ref = np.zeros(idx.size), np.zeros(idx.size)
+    for k, b in enumerate(idx):
+        p = XU.build(name, xref[b], x0[b], uref[b], abc[k], T=T)
+        for cand in (gpu, ref):
+            xs, us, (stat, eq, viol) = XU.arbiter(p, cand["x"][b], cand["u"][b])
+            if stat <= 1e-8 and eq <= 1e-9 and viol <= 1e-9:
+                break
+        else:
+            raise AssertionError(f"instance {b}: neither side's active set carries the minimiser")
+        d_gpu[k] = np.abs(gpu["u"][b] - us).max()
+        d_ref[k] = np.abs(ref["u"][b] - us).max()
+    return d_gpu, d_ref
+
+
 def test_65536_mpc_dsr_at_horizon_30():
     """mpc_dsr.py as it runs at T = 30: iterative_linear_mpc_control hard-wires the fixed-steer QP
     with stage weights Q 2^t (mpc_dsr.py:193,337-395).  65,536 instances cold, then warm-started
     from their own optimum: nothing fails, every returned point passes the solver-independent KKT
     certificate (1e-8), the objective is within 1e-4 relative of the oracle's wherever either side
-    solved, and the controls within the 1e-3 bar (median far below)."""
+    solved, and the controls within the 1e-3 bar: where engine and oracle are more than 1e-5
+    apart (the optimum is flat: cond(H) about 5e10) an extended-precision minimiser decides,
+    and the engine has to be within 1e-3 of it on every one of them."""
     from model_predictive_control_amd import engine
-    B = 65536
-    v, ov, x0, xref = make_problem("dsr_diff", B, seed=37, n_courses=64, T=30)
+    B, T = 65536, 30
+    v, ov, x0, xref = make_problem("dsr_diff", B, seed=37, n_courses=64, T=T)
     ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=16)
     out = engine.solve_batch(v, x0, xref)
     up = out["u"].cpu().numpy()
     ref2 = orc.iterative_batch(ov, x0, xref, up, None, nthreads=16)
     out2 = engine.solve_batch(v, x0, xref, up)
-    for o, r, ur in ((out, ref, None), (out2, ref2, up)):
+    ucold = np.zeros((B, 4, T))
+    for tag, o, r, ur in (("cold", out, ref, None), ("warm", out2, ref2, up)):
         st = o["status"].cpu().numpy()
         assert (st == 0).all(), np.bincount(st, minlength=5)
         worst = certify(ov, x0, xref, o, uref=ur)
         assert worst["stat"] <= 1e-8 and worst["neg"] <= 1e-8
+        g = {k: t.cpu().numpy() for k, t in o.items()}
         either = r["status"] <= 1                       # the GPU solved all of them
-        rel = np.abs(o["obj"].cpu().numpy() - r["obj"])[either] / np.maximum(1.0, np.abs(r["obj"][either]))
+        rel = np.abs(g["obj"] - r["obj"])[either] / np.maximum(1.0, np.abs(r["obj"][either]))
         assert rel.max() <= OBJ_BAR
         both = r["status"] == 0
-        du = np.abs(o["u"].cpu().numpy() - r["u"])[both].reshape(int(both.sum()), -1).max(axis=1)
-        # the optimum is flat (cond(H) about 5e10, and x - xref under weights of 2^29 carries 1e-6
-        # of rounding into either side's gradient): where the two are more than 1e-5 apart, which
-        # is rare, they are two points of the same cost to 1e-7
-        far = du > 1e-5
-        gap = (o["obj"].cpu().numpy() - r["obj"])[both][far] / np.maximum(1.0, np.abs(r["obj"][both][far]))
-        assert far.mean() <= 1e-3 and (gap <= 1e-7).all(), (far.sum(), gap)
-        assert du.max() <= 5e-3 and np.quantile(du, 0.999) <= U_BAR and np.median(du) <= 1e-7, (du.max(), np.median(du))
-        assert _constraint_violation(ov, o["u"].cpu().numpy(), np.asarray(ov.cold_start)[:ov.nu][None] if ur is None else ur[:, :, 0]) <= 1e-9
+        du = np.where(both, np.abs(g["u"] - r["u"]).reshape(B, -1).max(axis=1), 0.0)
+        far = np.nonzero(du > 1e-5)[0]
+        assert far.size <= 1e-3 * B, far.size
+        d_gpu, d_ref = _settle_with_the_arbiter("dsr_diff", T, v, x0, xref, ucold if ur is None else ur, g, r, far)
+        print(f"dsr_diff T=30 {tag}: {far.size} of {B} instances more than 1e-5 from the oracle (max {du.max():.2e}); "
+              f"from the extended-precision minimiser: engine max {d_gpu.max(initial=0.0):.2e}, oracle max {d_ref.max(initial=0.0):.2e}")
+        assert d_gpu.max(initial=0.0) <= U_BAR, (d_gpu.max(), d_ref.max())
+        assert np.median(du[both]) <= 1e-7
+        assert _constraint_violation(ov, g["u"], np.asarray(ov.cold_start)[:ov.nu][None] if ur is None else ur[:, :, 0]) <= 1e-9
 
 
 @pytest.mark.parametrize("name", ["sim_ackermann"])
