@@ -21,7 +21,7 @@ def _setup(name, B, seed, **overrides):
     return engine, v, ov, table, tabs, state, inst["course_id"], inst["pind"]
 
 
-@pytest.mark.parametrize("name", ["diff_drive", "dsr_ackermann", "dsr_diff", "sim_crab"])
+@pytest.mark.parametrize("name", ["diff_drive", "dsr_ackermann", "dsr_diff", "sim_crab", "sim_ackermann", "sim_diff"])
 def test_closed_loop_matches_oracle_loop(name):
     B, n = 96, 15
     engine, v, ov, table, tabs, state, cid, pind = _setup(name, B, 31)
@@ -31,18 +31,12 @@ def test_closed_loop_matches_oracle_loop(name):
     np.testing.assert_array_equal(loop.done.cpu().numpy(), want["done"])
     np.testing.assert_array_equal(loop.ticks.cpu().numpy(), want["ticks"])
     log, tind = loop.log.cpu().numpy(), loop.target_ind.cpu().numpy()
-    if name.startswith("sim_"):
-        # the mpc_sim chain of five QPs per tick agrees to ~1e-5 per tick and the closed loop
-        # amplifies it: compare the bulk, allow a stray vehicle
-        close = np.abs(log - want["log"]).reshape(n + 1, B, 4).max(axis=(0, 2)) < 1e-3
-        assert close.mean() >= 0.97
-        assert (tind == want["target_ind"]).mean() >= 0.97
-    else:
-        # each tick's QP answer agrees to ~1e-12; 15 ticks of plant integrate the differences
-        np.testing.assert_array_equal(tind, want["target_ind"])
-        np.testing.assert_allclose(log, want["log"], atol=1e-6, rtol=0)
-        np.testing.assert_allclose(loop.state.cpu().numpy(), want["state"], atol=1e-6, rtol=0)
-        np.testing.assert_allclose(loop.twist.cpu().numpy(), want["twist"], atol=1e-6, rtol=0)
+    # each tick's QP answer (the last of five chained ones for the mpc_sim variants) agrees to
+    # ~1e-12; 15 ticks of plant integrate the differences
+    np.testing.assert_array_equal(tind, want["target_ind"])
+    np.testing.assert_allclose(log, want["log"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(loop.state.cpu().numpy(), want["state"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(loop.twist.cpu().numpy(), want["twist"], atol=1e-6, rtol=0)
     # the vehicles moved along their courses
     assert (tind >= pind).all()
     assert np.median(np.hypot(*(log[-1][:, :2] - log[0][:, :2]).T)) > 0.05
@@ -126,4 +120,8 @@ def test_capture_of_a_workspace_loop_is_refused():
         loop.capture()
     loop.run(1)
     torch.cuda.synchronize()
-    assert (loop.out["status"].cpu().numpy() <= 1).mean() > 0.99 or (loop.uprev.abs().sum() > 0)
+    # the refused capture left the loop usable: the tick after it solves as usual
+    assert (loop.uprev.abs().sum() > 0)
+    loop.run(1)
+    torch.cuda.synchronize()
+    assert (loop.uprev.abs().sum() > 0) and int((loop.ticks == 2).sum().item()) == 2000

@@ -127,10 +127,10 @@ def test_sim_chained_solves_and_modes():
     for mode, name in (("ackermann", "sim_ackermann"), ("diff", "sim_diff"), ("crab", "sim_crab")):
         got = ctl.iterativeLMPC(xref, x0, None, None, None, None, mode)
         want = O.iterative_linear_mpc_control(O.variant(name), xref, x0, None)     # chain = 5
-        np.testing.assert_allclose(np.stack([got[0], got[2], got[1], got[3]]), want.u, atol=5e-5)
+        np.testing.assert_allclose(np.stack([got[0], got[2], got[1], got[3]]), want.u, atol=1e-7)
         got2 = ctl.iterativeLMPC(xref, x0, got[0], got[1], got[2], got[3], mode)
         want2 = O.iterative_linear_mpc_control(O.variant(name), xref, x0, want.u)
-        np.testing.assert_allclose(np.stack([got2[0], got2[2], got2[1], got2[3]]), want2.u, atol=5e-5)
+        np.testing.assert_allclose(np.stack([got2[0], got2[2], got2[1], got2[3]]), want2.u, atol=1e-7)
     t, x, y, yaw, vx, vy, w, state = ctl.doSimulation(cx, cy, cyaw, m.State(x=cx[0], y=cy[0], yaw=cyaw[0]),
                                                       mode="ackermann", max_ticks=5)
     assert len(x) == 6 and math.hypot(x[-1] - x[0], y[-1] - y[0]) > 0.05
@@ -153,10 +153,10 @@ def test_mpc_py_controller_tick():
         xref = O.prune_reference(pts, pose)
         r = O.iterative_linear_mpc_control(v, xref, list(pose), u)
         u = r.u
-        np.testing.assert_allclose(ctl.control_input_, u, atol=5e-5)
+        np.testing.assert_allclose(ctl.control_input_, u, atol=1e-6)
         vx, vy, w = O.wheel_to_twist(u[0, 0], u[1, 0], u[2, 0], u[3, 0])
         assert out.shape == (3, 1)
-        np.testing.assert_allclose(out.reshape(3), [vx, vy, w], atol=5e-5)
+        np.testing.assert_allclose(out.reshape(3), [vx, vy, w], atol=1e-6)
     assert len(ctl.predict_state_) == 20
 
 

@@ -52,8 +52,8 @@ def test_c_restatement_matches_numpy_twin(name):
     ref = [O.iterative_linear_mpc_control(ov, xref[b], x0[b], None) for b in range(24)]
     out = orc.iterative_batch(ov, x0, xref)
     # two interior-point runs stop at slightly different points: ~sqrt(mu) = 1e-6 on weakly
-    # active constraints; chained solves re-linearise at the previous answer
-    tol = 1e-5 if ov.chain > 1 else 1e-6
+    # active constraints
+    tol = 1e-6
     for b in range(24):
         assert out["status"][b] == ref[b].status == O.ST_OK
         assert np.abs(out["u"][b] - ref[b].u).max() < tol
