@@ -35,7 +35,16 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
 SOLVE_KERNEL = "k_solve_pair5<dual-steer, single QP>"   # two lanes per instance, T=5, everything on chip
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 SQ_FILE = os.path.join(ROOT, "profiles", "pair5_sq_counters.json")
+F64_FILE = os.path.join(ROOT, "profiles", "pair5_f64_counters.json")
 WARM_TICKS = 9     # closed-loop ticks run before the timed solve: the timed pass is tick 10
+# FP64 vector peak: 256 CUs x 4 SIMDs x 16 lanes/clock x 2 flops (fma) x 2.4 GHz (half the
+# packed-FP32 vector rate of 157.3 TFLOP/s); MFMA plays no part in this path
+FP64_VALU_PEAK_TFLOPS = 78.6
+# Untimed launches before the warm-up steps: an idle MI355X needs about 200 back-to-back
+# launches (20 ms) of this kernel to reach the clock it then holds (scripts/clock_ramp.py:
+# 108 us for the first 50 launches, 85, 83, 81, then 79.9 us for good); a 2 ms timed region
+# entered from idle measures the ramp, not the rate a running fleet sees.
+SETTLE_SECONDS = 0.06
 
 
 def ranks_to_spawn(gpus: int, env) -> int:
@@ -62,7 +71,7 @@ def recorded_counters(batch: int):
     doubled as gfx950 tallies 128-B requests at 64 B, plus WRITE_SIZE) and the fraction of wave
     cycles that issue a VALU instruction.  They are replays of files, not measurements of this
     run, and are dropped when the kernels have changed since they were recorded."""
-    out = {"traffic": None, "valu_busy_frac": None, "from_profiles": None}
+    out = {"traffic": None, "valu_busy_frac": None, "f64": None, "from_profiles": None}
     now = kernel_source_hash()
     src = {}
     try:
@@ -81,9 +90,31 @@ def recorded_counters(batch: int):
             src["valu_busy_frac"] = {"file": os.path.relpath(SQ_FILE, ROOT), "csrc_sha": rec["csrc_sha"]}
     except (OSError, ValueError, KeyError):
         pass
+    try:
+        with open(F64_FILE) as f:
+            rec = json.load(f)
+        if rec.get("batch") == batch and rec.get("csrc_sha") == now:
+            out["f64"] = rec
+            src["roofline_valu"] = {"file": os.path.relpath(F64_FILE, ROOT), "csrc_sha": rec["csrc_sha"]}
+    except (OSError, ValueError, KeyError):
+        pass
     if src:
         out["from_profiles"] = src
     return out
+
+
+def settle(step, seconds: float = SETTLE_SECONDS):
+    """Untimed back-to-back launches until the GPU holds its clock (see SETTLE_SECONDS)."""
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+        n += 50
+    return n
 
 
 def algorithmic_bytes(nu: int, T: int) -> int:
@@ -160,6 +191,7 @@ def other_configs(steps: int = 3):
     courses = workload.make_courses(64, seed=1001)
     for name, B, T, kernel in (("diff_drive", 65536, None, "k_solve_pair5<diff-drive>"),
                                ("diff_drive", 262144, None, "k_solve_pair5<diff-drive>"),
+                               ("sim_ackermann", 65536, None, "k_solve_pair5<dual-steer, chain of 5 QPs> (MPC.iterativeLMPC, mpc_sim.py:284-310)"),
                                ("mpc_py", 65536, None, "k_solve_stage<dual-steer>"),
                                ("dsr_diff", 65536, 30, "k_solve_stage<dual-steer>"),
                                ("dsr_ackermann", 65536, 30, "k_solve_stage<dual-steer>")):
@@ -174,23 +206,70 @@ def other_configs(steps: int = 3):
         for start, u in (("cold", None), ("warm", up)):
             if start == "cold" and T != 30:
                 continue
-            engine.solve_batch(v, d_x0, d_xref, u, out=out)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
+            n = steps if v.T > 5 else 40 * steps      # the short kernels need more launches for a stable figure
+            for _ in range(max(1, n // 4)):
                 engine.solve_batch(v, d_x0, d_xref, u, out=out)
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
+            t0 = time.perf_counter()
+            for _ in range(n):
+                engine.solve_batch(v, d_x0, d_xref, u, out=out)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
             res.append({"workload": f"{name} T={v.T} batch {B} {start}", "value": B / dt, "unit": "solves/s",
                         "ms_per_step": dt * 1e3, "kernel": kernel,
                         "solved_fraction": float((out["status"] <= 1).float().mean().item()),
                         "failed": int((out["status"] == 4).sum().item()),
                         "algorithmic_GBps": ab * B / dt / 1e9})
     res.append(closed_loop_tick())
+    res.append(mixed_sweep_one_gpu())
     return res
 
 
-def closed_loop_tick(B: int = BATCH, n: int = 50):
+def fused_tick_bytes(nu: int, T: int) -> int:
+    """Compulsory traffic of one fused closed-loop tick per vehicle: the iterative entry's bytes with
+    the 24 (T+1)-byte reference window read replaced by state 32 B + previous index 4 B + course id
+    4 B + ten course points and the end point 176 B, plus the new index 4 B written."""
+    return algorithmic_bytes(nu, T) - 24 * (T + 1) + 32 + 4 + 4 + 176 + 4
+
+
+def mixed_sweep_one_gpu(total: int = MIXED_TOTAL, steps: int = 3):
+    """The 4 x 1,048,576 mixed-variant sweep on this one GPU (the strong-scaling workload at N = 1):
+    four launches per step; the gather of the results into pinned host memory timed beside it."""
+    import torch
+    from model_predictive_control_amd import engine
+    parts = mixed_inputs(0, 1, total)
+
+    def step():
+        for p in parts:
+            engine.solve_batch(p["v"], p["x0"], p["xref"], p["uprev"], out=p["out"])
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    host = [{k: torch.empty(t.shape, dtype=t.dtype).pin_memory() for k, t in p["out"].items()} for p in parts]
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    for p, h in zip(parts, host):
+        for k, t in p["out"].items():
+            h[k].copy_(t, non_blocking=True)
+    torch.cuda.synchronize()
+    gather_s = time.perf_counter() - tg
+    n = sum(p["n"] for p in parts)
+    nbytes = sum(t.numel() * t.element_size() for h in host for t in h.values())
+    ab = sum(algorithmic_bytes(p["v"].nu, p["v"].T) * p["n"] for p in parts)
+    return {"workload": f"mixed sweep {n} instances ({', '.join(MIXED_VARIANTS)}; T=5), one GPU", "value": n / dt, "unit": "solves/s",
+            "ms_per_step": dt * 1e3, "kernel": "k_solve_pair5, four instantiations, one launch per variant",
+            "solved_fraction": sum(int((p["out"]["status"] <= 1).sum().item()) for p in parts) / n,
+            "failed": sum(int((p["out"]["status"] == 4).sum().item()) for p in parts),
+            "algorithmic_GBps": ab / dt / 1e9,
+            "gather": {"ms": gather_s * 1e3, "bytes": nbytes, "GBps": nbytes / gather_s / 1e9,
+                       "how": "u, x, obj, status, iters copied into pinned host memory; not part of value"}}
+
+
+def closed_loop_tick(B: int = BATCH, n: int = 200):
     """The fused tick (reference window from the course tables on the device -> solve -> state
     advance and goal test, no host round trip) of a fleet of the headline variant: per vehicle
     and tick it reads the state (32 B), previous index and course id (8 B), ten course points
@@ -202,7 +281,7 @@ def closed_loop_tick(B: int = BATCH, n: int = 50):
     courses = workload.make_courses(1024, seed=1001)
     inst = workload.make_instances(courses, B, seed=2003)
     loop = engine.ClosedLoop(v, engine.CourseTable(courses), inst["state"][:, :4].copy(), inst["course_id"], pind0=inst["pind"])
-    loop.run(5)
+    loop.run(100)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loop.run(n)
@@ -210,6 +289,8 @@ def closed_loop_tick(B: int = BATCH, n: int = 50):
     dt = (time.perf_counter() - t0) / n
     return {"workload": f"closed-loop tick {VARIANT} T={v.T} fleet {B}", "value": B / dt, "unit": "vehicle-ticks/s",
             "ms_per_step": dt * 1e3, "kernel": "k_nearest_ref + k_solve_pair5 + k_advance",
+            "algorithmic_bytes_per_vehicle_tick": fused_tick_bytes(v.nu, v.T),
+            "algorithmic_GBps": fused_tick_bytes(v.nu, v.T) * B / dt / 1e9,
             "still_driving": int((loop.done == 0).sum().item()), "failed": int((loop.out["status"] == 4).sum().item())}
 
 
@@ -315,20 +396,31 @@ def main():
         units_here = sum(p["n"] for p in parts)
         bytes_here = sum(algorithmic_bytes(p["v"].nu, p["v"].T) * p["n"] for p in parts)
 
+    settled = settle(step)
     for _ in range(args.warmup):
         step()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # HIP events on the launch stream bracket the K steps (one before the first launch, one after
+    # the last: an event between every two launches costs about 6 us of dispatch each)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
+    ev0.record()
     for k in range(args.steps):
-        ev[k].record()                                 # same stream the kernels are launched on
         step()
-    ev[args.steps].record()
+    ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dist, red_dev)
     ok = int(sharding.sum_over_ranks(ok, dist, red_dev))
     units_all = int(sharding.sum_over_ranks(units_here, dist, red_dev))
+    kernel_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
+    # latency of one batch call, outside the timed region: every step bracketed by its own events
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    for k in range(args.steps):
+        ev[k].record()
+        step()
+    ev[args.steps].record()
+    torch.cuda.synchronize()
     per_step_ms = np.array([ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)])
 
     gather_ms = None
@@ -346,7 +438,6 @@ def main():
         gathered_bytes = sharding.sum_over_ranks(sum(t.numel() * t.element_size() for h in host for t in h.values()), dist, red_dev)
 
     if rank == 0:
-        kernel_s = float(per_step_ms.mean()) * 1e-3
         achieved = bytes_here / kernel_s / 1e9
         line = {
             "metric": "MPC solves/sec (T=5 bicycle, batch 64k)",
@@ -362,6 +453,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "solved_fraction": ok / units_all,
+            "settle_launches": settled,
+            "settle_note": f"{settled} untimed steps ({SETTLE_SECONDS * 1e3:.0f} ms) before the warm-up steps bring the GPU from idle "
+                           "to the clock it holds under this load (scripts/clock_ramp.py)",
         }
         if workload_name == "headline":
             line["config"] = {"workload": f"{B} independent T=5 general-bicycle (dual-steer NX=3 NU=4, ackermann "
@@ -375,8 +469,9 @@ def main():
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": achieved / HBM_PEAK_GBS, "traffic": rec["traffic"],
                                 "kernel": SOLVE_KERNEL, "kernel_ms": kernel_s * 1e3,
-                                "kernel_ms_note": "HIP events on the launch stream, back-to-back launches: includes the ~4 us "
-                                                  "dispatch gap between consecutive kernels that a kernel trace leaves out",
+                                "kernel_ms_note": "HIP events on the launch stream around the K back-to-back launches of the timed "
+                                                  "region, divided by K: includes the dispatch gap between consecutive kernels "
+                                                  "that a kernel trace leaves out",
                                 "algorithmic_bytes_per_solve": algorithmic_bytes(v.nu, v.T),
                                 "valu_busy_frac": rec["valu_busy_frac"],
                                 "from_profiles": rec["from_profiles"],
@@ -385,6 +480,18 @@ def main():
                                                       "kernel sources have changed since",
                                 "note": "the solve is FP64-VALU issue bound (5 interior-point iterations + ~4 active-set "
                                         "rounds, one 10x10 Cholesky each, per instance); HBM fraction reported as the task asks"}
+            f64 = rec["f64"]
+            if f64 is not None:
+                # flops of one launch from the recorded FP64 instruction counts (every wave instruction
+                # counted at 64 lanes: an upper bound where lanes are masked off) over THIS run's kernel time
+                tf = float(f64["flops_per_launch"]) / kernel_s / 1e12
+                line["roofline_valu"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_launch": f64["flops_per_launch"],
+                                         "flops_per_solve": f64["flops_per_launch"] / B,
+                                         "f64_instructions_per_wave": f64["per_wave"],
+                                         "note": "flops = 64 x (2 FMA + MUL + ADD + TRANS) FP64 wave instructions of one launch, from "
+                                                 "a recorded SQ_INSTS_VALU_*_F64 counter pass (replayed, see roofline.from_profiles); "
+                                                 "time = this run's HIP-event kernel time"}
         else:
             line["metric"] = "MPC solves/sec (T=5 mixed-model sweep, 4M instances)"
             line["config"] = {"workload": f"{units_all} instances, a quarter each of {', '.join(MIXED_VARIANTS)} (T=5), sorted "

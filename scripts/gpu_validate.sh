@@ -5,7 +5,7 @@
 # Every GPU step has its own time limit and the chain stops at the first failure.
 # Afterwards, here: python scripts/summarise_profiles.py <tag>  (writes profiles/).
 set -o pipefail
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -14,6 +14,7 @@ pmc() {  # pmc <dir> <counters...> -- <script args...>
   timeout -s KILL 150 rocprofv3 --pmc "${ctr[@]}" --output-format csv -d $OUT/$d -o p -- python3 "$@" > $OUT/$d.log 2>&1
 }
 SQ_A="SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES"
+SQ_F64="SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU"
 SQ_B="SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_LDS"
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 300 --timeout-method thread > $OUT/gputests.log 2>&1 \
  && tail -3 $OUT/gputests.log \
@@ -26,6 +27,15 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 30
  && pmc pmc_write WRITE_SIZE -- bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs \
  && pmc sq5_a $SQ_A -- scripts/prof_solve.py dsr_ackermann 65536 5 \
  && pmc sq5_b $SQ_B -- scripts/prof_solve.py dsr_ackermann 65536 5 \
+ && pmc sq5_f64 $SQ_F64 -- scripts/prof_solve.py dsr_ackermann 65536 5 \
+ && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ch_trace -o p -- python3 scripts/prof_solve.py sim_ackermann 65536 20 > $OUT/ch_trace.log 2>&1 \
+ && pmc ch_sq_a $SQ_A -- scripts/prof_solve.py sim_ackermann 65536 5 \
+ && pmc ch_sq_b $SQ_B -- scripts/prof_solve.py sim_ackermann 65536 5 \
+ && pmc ch_fetch FETCH_SIZE -- scripts/prof_solve.py sim_ackermann 65536 5 \
+ && pmc ch_write WRITE_SIZE -- scripts/prof_solve.py sim_ackermann 65536 5 \
+ && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wv_trace -o p -- python3 scripts/prof_solve.py dsr_ackermann 1280 20 30 > $OUT/wv_trace.log 2>&1 \
+ && pmc wv_sq_a $SQ_A -- scripts/prof_solve.py dsr_ackermann 1280 5 30 \
+ && pmc wv_sq_b $SQ_B -- scripts/prof_solve.py dsr_ackermann 1280 5 30 \
  && pmc p10_fetch FETCH_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \
  && pmc p10_write WRITE_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \
  && pmc p10_sq $SQ_A -- scripts/prof_solve.py mpc_py 32768 3 \
@@ -40,4 +50,6 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 30
  && pmc lp_fetch FETCH_SIZE -- scripts/prof_loop.py \
  && pmc lp_write WRITE_SIZE -- scripts/prof_loop.py \
  && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sd_trace -o p -- python3 scripts/prof_solve.py dsr_diff 65536 5 30 > $OUT/sd_trace.log 2>&1 \
+ && pmc sd_fetch FETCH_SIZE -- scripts/prof_solve.py dsr_diff 65536 3 30 \
+ && pmc sd_write WRITE_SIZE -- scripts/prof_solve.py dsr_diff 65536 3 30 \
  && echo validate-done

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r2"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r3"
 OUT = os.path.join(ROOT, "gpurun_out", tag)
 PROF = os.path.join(ROOT, "profiles")
 sha = bench.kernel_source_hash()
@@ -97,6 +97,37 @@ if pw:
            "how": how + "; counters summed over the launch and divided by its waves; SQ_*_CYCLES and SQ_ACTIVE_* tick once per 4 clocks"}
     json.dump(rec, open(os.path.join(PROF, "pair5_sq_counters.json"), "w"), indent=1)
     print("headline valu busy", rec["valu_busy_frac"], "VALU/wave", pw.get("SQ_INSTS_VALU"))
+pw = sq(["sq5_f64"], "k_solve_pair5")
+if pw and pw.get("SQ_INSTS_VALU_FMA_F64") is not None:
+    waves = 65536 // 32
+    per = {k: pw.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")}
+    flops_wave = 64.0 * (2.0 * per["SQ_INSTS_VALU_FMA_F64"] + per["SQ_INSTS_VALU_MUL_F64"] + per["SQ_INSTS_VALU_ADD_F64"] + per["SQ_INSTS_VALU_TRANS_F64"])
+    rec = {"kernel": "k_solve_pair5<dual-steer, single QP>", "batch": 65536, "csrc_sha": sha, "per_wave": per, "waves": waves,
+           "flops_per_launch": flops_wave * waves,
+           "how": how + "; wave instructions per wave; flops = 64 lanes x (2 FMA + MUL + ADD + TRANS), masked-off lanes counted"}
+    json.dump(rec, open(os.path.join(PROF, "pair5_f64_counters.json"), "w"), indent=1)
+    print("headline f64 instr/wave", per, "flops/solve", flops_wave * waves / 65536)
+# chained pair kernel (MPC.iterativeLMPC: five QPs per call)
+st = kernel_stats("ch_trace", "p", f"{rnd}_chain_kernel_stats.csv")
+t = traffic("ch_fetch", "ch_write", "k_solve_pair5")
+pw = sq(["ch_sq_a", "ch_sq_b"], "k_solve_pair5")
+if t or pw:
+    ns, calls = avg_ns(st, "k_solve_pair5<1, true>")
+    rec = {"kernel": "k_solve_pair5<dual-steer, chain>", "variant": "sim_ackermann", "batch": 65536, "csrc_sha": sha, "avg_ns": ns,
+           "launches": calls, "algorithmic_bytes": 65536 * 649, "traffic": t, "per_wave": pw,
+           "valu_busy_frac": (pw.get("SQ_ACTIVE_INST_VALU", 0.0) / pw["SQ_WAVE_CYCLES"]) if pw and pw.get("SQ_WAVE_CYCLES") else None, "how": how}
+    json.dump(rec, open(os.path.join(PROF, f"{rnd}_chain_counters.json"), "w"), indent=1)
+    print("chain kernel", ns, "ns", t and t["bytes_per_launch"])
+# wavefront-per-instance kernel, T = 30, the batch the chip holds at once
+st = kernel_stats("wv_trace", "p", f"{rnd}_wave_T30_kernel_stats.csv")
+pw = sq(["wv_sq_a", "wv_sq_b"], "k_solve_wave")
+if pw:
+    ns, calls = avg_ns(st, "k_solve_wave")
+    rec = {"kernel": "k_solve_wave<dual-steer>", "variant": "dsr_ackermann", "T": 30, "batch": 1280, "csrc_sha": sha, "avg_ns": ns,
+           "launches": calls, "per_wave": pw,
+           "valu_busy_frac": (pw.get("SQ_ACTIVE_INST_VALU", 0.0) / pw["SQ_WAVE_CYCLES"]) if pw.get("SQ_WAVE_CYCLES") else None, "how": how}
+    json.dump(rec, open(os.path.join(PROF, f"{rnd}_wave_T30_counters.json"), "w"), indent=1)
+    print("wave kernel T30", ns, "ns")
 # T = 10 kernel
 t = traffic("p10_fetch", "p10_write", "k_solve_pair10")
 pw = sq(["p10_sq"], "k_solve_pair10")
@@ -126,6 +157,15 @@ if t:
            "hbm_GBps": (t["bytes_per_launch"]) / ns if ns else None, "algorithmic_bytes": 65536 * 3449, "how": how}
     json.dump(rec, open(os.path.join(PROF, f"{rnd}_stage_T30_traffic.json"), "w"), indent=1)
     print("stage T30", rec["avg_ns"], "ns", t["bytes_per_launch"] / 1e9, "GB per launch")
+t = traffic("sd_fetch", "sd_write", "k_solve_stage")
+if t:
+    sd = {r["Name"]: r for r in csv.DictReader(open(os.path.join(PROF, f"{rnd}_stage_T30_dsr_diff_kernel_stats.csv")))} if os.path.exists(os.path.join(PROF, f"{rnd}_stage_T30_dsr_diff_kernel_stats.csv")) else {}
+    ns, calls = avg_ns(sd, "k_solve_stage")
+    rec = {"kernel": "k_solve_stage<dual steer>", "variant": "dsr_diff", "T": 30, "batch": 65536, "csrc_sha": sha,
+           "avg_ns": ns, "launches": calls, "hbm_read_bytes": t["fetch_bytes"], "hbm_write_bytes": t["write_bytes"],
+           "hbm_GBps": (t["bytes_per_launch"]) / ns if ns else None, "algorithmic_bytes": 65536 * 3449, "how": how}
+    json.dump(rec, open(os.path.join(PROF, f"{rnd}_stage_T30_dsr_diff_traffic.json"), "w"), indent=1)
+    print("stage T30 dsr_diff", ns, "ns", t["bytes_per_launch"] / 1e9, "GB per launch (median over cold and warm launches)")
 pw = sq(["st_sq"], "k_solve_stage")
 if pw:
     json.dump({"kernel": "k_solve_stage<dual steer>", "T": 30, "batch": 65536, "csrc_sha": sha, "per_wave": pw, "how": how},
