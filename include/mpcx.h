@@ -110,11 +110,20 @@ int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const d
 
 /* No counterpart in the reference: mpcx_solve_batch for callers that cannot allocate device
  * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
- * Same arguments, same kernels, same results; the call allocates and frees nothing, creates no
- * event and never synchronises.  Where the solve needs a workspace (see mpcx_workspace_bytes)
- * it uses a fixed array of mpcx_static_workspace_bytes() bytes that lives in the library's
- * device image on every GPU; a batch whose workspace (440 T bytes per instance, B rounded up
- * to a multiple of 64) exceeds it is rejected with MPCX_E_NOMEM and nothing is launched.
+ * Same arguments, same kernels, same results; the call itself allocates and frees nothing,
+ * creates no event and never synchronises.  Where the solve needs a workspace (see
+ * mpcx_workspace_bytes) it uses a fixed array of mpcx_static_workspace_bytes() bytes (64 MiB)
+ * that lives in the library's device image: every GPU on which the library's code object is
+ * loaded holds it until the process ends, whether or not this entry point is ever called.  A
+ * batch whose workspace (440 T bytes per instance, B rounded up to a multiple of 64) exceeds it
+ * is rejected with MPCX_E_NOMEM and nothing is launched.
+ * Set-up, once per device and outside any stream capture: call mpcx_static_workspace_bytes()
+ * with that device current (it looks up the device's copy of the array, which loads the code
+ * object there if need be), then make one call of this entry point of the kind that will be
+ * captured or timed: the first dispatch of a kernel on a queue lets the HIP runtime set up the
+ * kernel's private-memory segment (the stage-wise kernel keeps 216 bytes per lane there), which
+ * is the runtime's allocation, not this library's.  After that warm-up call the device's free
+ * memory does not change over further calls, and the call can be recorded into a HIP graph.
  * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different
  * streams, or different host threads) race; calls on one stream are safe. */
 int mpcx_solve_batch_noalloc(const mpcx_variant *v, int64_t B, const double *x0, const double *xref,

@@ -61,13 +61,17 @@ def course_table(cx, cy, cyaw):
     keyed by identity would miss), so a tick costs a hash of the lists instead of an upload."""
     ax, ay, aw = (np.ascontiguousarray(a, dtype=np.float64) for a in (cx, cy, cyaw))
     key = (ax.size, hash(ax.tobytes()), hash(ay.tobytes()), hash(aw.tobytes()))
-    table = _TABLES.pop(key, None)
-    if table is None:
-        table = engine.CourseTable([(ax, ay, aw)])
+    entry = _TABLES.pop(key, None)
+    # a hit counts only if the arrays themselves are equal: two courses may share a hash
+    if entry is not None and not (np.array_equal(entry[1], ax) and np.array_equal(entry[2], ay)
+                                  and np.array_equal(entry[3], aw)):
+        entry = None
+    if entry is None:
+        entry = (engine.CourseTable([(ax, ay, aw)]), ax.copy(), ay.copy(), aw.copy())
         while len(_TABLES) >= _TABLES_MAX:
             _TABLES.pop(next(iter(_TABLES)))
-    _TABLES[key] = table
-    return table
+    _TABLES[key] = entry
+    return entry[0]
 
 
 def nearest_ref_one(mode, T, dt, param, state, cx, cy, cyaw, pind, n_search, sign=True):
@@ -109,17 +113,21 @@ def closed_loop_one(v, cx, cy, cyaw, state, goal_dis, stop_speed, dt, max_time, 
         loop.run(min(chunk, limit - loop.n_done_ticks))
         done = int(loop.done.cpu()[0])
     n = int(loop.ticks.cpu()[0])
-    if done == 2:
-        raise ValueError("min() arg is an empty sequence")
     log = loop.log[:n + 1, 0].cpu().numpy()
     tw = loop.twist_log[:n + 1, 0].cpu().numpy()
+    # the reference logs the initial state's own vy and w as the first entry (mpc_dsr.py:531-536)
+    tw[0, 0], tw[0, 1] = float(getattr(state, "vy", 0.0)), float(getattr(state, "w", 0.0))
     t = [0.0]
     for _ in range(n):
         t.append(t[-1] + dt)
+    # the reference has advanced `state` in place tick by tick, also when it then raises
     state.x, state.y, state.yaw, state.vx = (float(a) for a in log[n])
-    if hasattr(state, "vy"):
-        state.vy = float(tw[n, 0])
-    if hasattr(state, "w"):
-        state.w = float(tw[n, 1])
+    if n > 0:
+        if hasattr(state, "vy"):
+            state.vy = float(tw[n, 0])
+        if hasattr(state, "w"):
+            state.w = float(tw[n, 1])
+    if done == 2:
+        raise ValueError("min() arg is an empty sequence")
     return dict(t=t, x=log[:, 0].tolist(), y=log[:, 1].tolist(), yaw=log[:, 2].tolist(), vx=log[:, 3].tolist(),
                 vy=tw[:, 0].tolist(), w=tw[:, 1].tolist(), goal=done == 1, target_ind=int(loop.target_ind.cpu()[0]))

@@ -11,11 +11,15 @@ ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "mpcx_kernels.hip")
 DEPS = sorted(os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc"))) + [os.path.join(ROOT, "include", "mpcx.h")]
 OUT = os.path.join(HERE, "lib", "libmpcx.so")
+# the same sources with -DMPCX_TEST_HOOKS: adds the first-generation one-lane-per-instance kernel
+# and the environment variables that route solves to a chosen kernel; loaded only by
+# tests/test_gpu_cross_kernels.py (through MPCX_LIB), never by the package itself
+OUT_HOOKS = os.path.join(HERE, "lib", "libmpcx_hooks.so")
 LOG = os.path.join(HERE, "lib", "build_resource_usage.txt")
 
 
 def up_to_date() -> bool:
-    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+    return all(os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in DEPS) for o in (OUT, OUT_HOOKS))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -25,11 +29,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wno-pass-failed", "-Rpass-analysis=kernel-resource-usage",
-           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", OUT, SRC]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc")]
+    # both libraries at once: the compile is one translation unit each, about a minute
+    hooks = subprocess.Popen(cmd + ["-DMPCX_TEST_HOOKS", "-o", OUT_HOOKS, SRC], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    r = subprocess.run(cmd + ["-o", OUT, SRC], capture_output=True, text=True)
+    _, hooks_err = hooks.communicate()
     if r.returncode != 0:
         sys.stderr.write(r.stderr)
         raise RuntimeError("hipcc failed building libmpcx.so")
+    if hooks.returncode != 0:
+        sys.stderr.write(hooks_err)
+        raise RuntimeError("hipcc failed building libmpcx_hooks.so")
     rows, cur = [], None
     for line in r.stderr.splitlines():
         m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|"

@@ -198,6 +198,9 @@ __device__ __forceinline__ void run_instance(S &s, const SolveArgs &a, int64_t b
     }
 }
 
+// One lane per instance with the dense condensed QP (the first-generation kernel): built only
+// into the test-hook library (-DMPCX_TEST_HOOKS), where the cross-kernel tests route to it.
+#ifdef MPCX_TEST_HOOKS
 template <int MODEL, int T, bool CHAIN>
 __global__ __launch_bounds__(kWave) void k_solve_reg(SolveArgs a)
 {
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(kWave) void k_solve_reg(SolveArgs a)
     if (!live) b = a.B - 1;   // idle lanes redo the last instance so wave votes stay uniform
     run_instance<MODEL, true, CHAIN>(s, a, b, live);
 }
+#endif
 
 // Two lanes per instance (T = 5, every bound present, single QP per call).
 #ifndef MPCX_PAIR_OCC
@@ -1189,8 +1193,17 @@ static bool boxes_present(const mpcx_variant *v)
     return (fin(v->umax[0]) || fin(v->umax[2])) && (fin(v->umax[1]) || fin(v->umax[3]));
 }
 
-// test hook: MPCX_SINGLE_LANE=1 routes T = 5 solves to the one-lane-per-instance kernel
+// Routing hooks of the test library only (-DMPCX_TEST_HOOKS; the product library reads no
+// environment variable): MPCX_SINGLE_LANE=1 routes T = 5 solves to the one-lane-per-instance
+// kernel; MPCX_STAGEWISE=1 routes every horizon other than 5 to the stage-wise kernel, =0 every
+// one the wavefront-per-instance kernel can take to that kernel.
+#ifdef MPCX_TEST_HOOKS
 static const bool g_force_single_lane = [] { const char *e = getenv("MPCX_SINGLE_LANE"); return e && e[0] == '1'; }();
+static const int g_stagewise = [] { const char *e = getenv("MPCX_STAGEWISE"); return e ? atoi(e) : -1; }();
+#else
+constexpr bool g_force_single_lane = false;
+constexpr int g_stagewise = -1;
+#endif
 
 // grow-only per-device workspace of the stage-wise kernel
 static std::mutex g_ws_mutex;
@@ -1208,10 +1221,6 @@ static int64_t stage_chunk(int64_t B)
     const int64_t cap = 262144;
     return B < cap ? ((B + kWave - 1) / kWave) * kWave : cap;
 }
-
-// test hook: MPCX_STAGEWISE=1 routes every horizon other than 5 to the stage-wise kernel,
-// =0 every one the wavefront-per-instance kernel can take to that kernel
-static const int g_stagewise = [] { const char *e = getenv("MPCX_STAGEWISE"); return e ? atoi(e) : -1; }();
 
 // Largest batch the wavefront-per-instance kernel takes: what the chip holds at once (256 CUs,
 // per CU as many wavefronts as LDS and registers allow).  One such round takes less than the
@@ -1326,6 +1335,7 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
         return 0;
     }
     case kPathReg5: {
+#ifdef MPCX_TEST_HOOKS
         const dim3 grid((unsigned)((a.B + kWave - 1) / kWave));
         if (m == 0) {
             if (chained) hipLaunchKernelGGL((k_solve_reg<0, 5, true>), grid, block, 0, st, a);
@@ -1337,6 +1347,9 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_solve_reg launch");
         return 0;
+#else
+        return fail(MPCX_E_UNSUPPORTED, "the one-lane-per-instance kernel is part of the test-hook library only");
+#endif
     }
     case kPathPair10: {
         const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
@@ -1502,7 +1515,16 @@ int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const d
     return launch_solve(a, (hipStream_t)stream);
 }
 
-int64_t mpcx_static_workspace_bytes(void) { return (int64_t)kScratchBytes; }
+// Also the set-up call of mpcx_solve_batch_noalloc for the current device: the address of that
+// device's copy of the array is looked up here (loading the code object on the device if this
+// is the library's first use of it), so that the solve call itself does no lookup.
+int64_t mpcx_static_workspace_bytes(void)
+{
+    int dev = 0;
+    double *p = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) (void)scratch_of_device(dev, &p);
+    return (int64_t)kScratchBytes;
+}
 
 int mpcx_solve_batch_noalloc(const mpcx_variant *v, int64_t B, const double *x0, const double *xref,
                              const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,

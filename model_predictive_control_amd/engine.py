@@ -263,6 +263,7 @@ class ClosedLoop:
         # (vy, w) applied per tick, kept beside the state log when asked for (row 0: at rest)
         self.twist_log = torch.zeros((log_ticks + 1, B, 2), dtype=torch.float64, device=dev) if log_ticks and log_twist else None
         self.n_done_ticks = 0
+        self._solve = self.lib.mpcx_solve_batch
         self._initial_alignment()
 
     def _initial_alignment(self):
@@ -297,9 +298,9 @@ class ClosedLoop:
         t, v, lib, st = self.table, self.v, self.lib, _stream()
         self.prepare()
         o = self.out
-        _lib.check(lib.mpcx_solve_batch(C.byref(v), self.B, _ptr(self.x0), _ptr(self.xref), _ptr(self.uprev),
-                                        _ptr(self.has_prev), _ptr(o["u"]), _ptr(o["x"]), _ptr(o["obj"]),
-                                        _ptr(o["status"]), _ptr(o["iters"]), st))
+        _lib.check(self._solve(C.byref(v), self.B, _ptr(self.x0), _ptr(self.xref), _ptr(self.uprev),
+                               _ptr(self.has_prev), _ptr(o["u"]), _ptr(o["x"]), _ptr(o["obj"]),
+                               _ptr(o["status"]), _ptr(o["iters"]), st))
         k = self.n_done_ticks + 1
         log = self.log[k] if self.log is not None and k < self.log.shape[0] else None
         _lib.check(lib.mpcx_advance_batch(C.byref(v), self.B, self.goal_dis, self.stop_speed, _ptr(o["u"]),
@@ -314,15 +315,21 @@ class ClosedLoop:
 
     def capture(self):
         """Records two consecutive ticks (one per warm-start buffer) as a HIP graph; `run`
-        then replays it: 8 launches become one graph launch.  Needs the register/LDS-resident
-        solve kernels (T = 5, every bound finite): they allocate nothing.  Logging is off
-        in a captured loop.  Capturing itself advances the loop by two (warm-up) ticks."""
+        then replays it: 8 launches become one graph launch.  The register/LDS-resident solve
+        kernels allocate nothing; a loop whose solve streams through a workspace switches, from
+        here on, to the entry point that uses the library's fixed workspace (64 MiB per GPU,
+        shared by everything on that GPU that takes this route: one such loop at a time) and is
+        refused if it does not fit.  Logging is off in a captured loop.  Capturing itself
+        advances the loop by two (warm-up) ticks."""
         if self.log is not None:
             raise _lib.MpcxError("a logging loop cannot be captured: the log slot changes every tick")
         need = self.lib.mpcx_workspace_bytes(C.byref(self.v), self.B)
         if need != 0:
-            raise _lib.MpcxError(f"this loop's solve takes the workspace path ({need} bytes): it allocates and "
-                                 "waits on an event, which a stream capture does not allow")
+            have = self.lib.mpcx_static_workspace_bytes()      # also the per-device set-up of that entry point
+            if need > have:
+                raise _lib.MpcxError(f"this loop's solve needs a workspace of {need} bytes: the growing one is allocated and "
+                                     f"waited for on an event, which a stream capture does not allow, and the fixed one holds {have}")
+            self._solve = self.lib.mpcx_solve_batch_noalloc
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -100,27 +100,50 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def spawn_ranks(cmd: Sequence[str], world: int, env=None, timeout=None) -> int:
+def spawn_ranks(cmd: Sequence[str], world: int, env=None, timeout=900.0) -> int:
     """Starts `world` fresh processes of `cmd`, one rank each (RANK, LOCAL_RANK, WORLD_SIZE,
     MASTER_ADDR = 127.0.0.1 and a free MASTER_PORT in their environment, the way
-    torch.distributed.run does), waits for all and returns the largest exit code.  The caller must
-    not have touched the GPU: the children are new programs, nothing is inherited or replaced."""
+    torch.distributed.run does) and polls them all.  The first rank that exits with an error ends
+    the job: its siblings, which would otherwise sit in the rendezvous or a barrier until the
+    collective's own timeout, are terminated (then killed) and that exit code is returned; so is
+    124 once `timeout` seconds (None = no limit) have passed.  Otherwise 0 when every rank has
+    ended.  The caller must not have touched the GPU: the children are new programs, nothing is
+    inherited or replaced."""
     import os
     import subprocess
+    import time
     port = free_port()
     procs = []
     for r in range(world):
         e = dict(os.environ if env is None else env)
         e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen(list(cmd), env=e))
-    rc = 0
-    for pr in procs:
-        try:
-            rc = max(rc, abs(pr.wait(timeout=timeout)))
-        except subprocess.TimeoutExpired:
-            pr.kill()
-            rc = max(rc, 124)
-    return rc
+
+    def stop_all():
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        t_end = time.monotonic() + 10.0
+        for pr in procs:
+            try:
+                pr.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                pr.kill()
+                pr.wait()
+
+    t0 = time.monotonic()
+    while True:
+        codes = [pr.poll() for pr in procs]
+        bad = [abs(c) for c in codes if c not in (None, 0)]
+        if bad:
+            stop_all()
+            return bad[0]
+        if all(c == 0 for c in codes):
+            return 0
+        if timeout is not None and time.monotonic() - t0 > timeout:
+            stop_all()
+            return 124
+        time.sleep(0.05)
 
 
 def whole_job_rate(units_per_rank: int, world: int, steps: int, elapsed_max: float) -> float:

@@ -110,18 +110,29 @@ def test_graph_replay_equals_eager_ticks():
     np.testing.assert_array_equal(graph.last_u.cpu().numpy(), eager.last_u.cpu().numpy())
 
 
-def test_capture_of_a_workspace_loop_is_refused():
-    """A loop whose solve takes the workspace path (T = 30 beyond the chip-resident batch) would
-    allocate and wait on an event inside the capture: capture() must refuse it up front."""
+def test_capture_of_a_workspace_loop():
+    """A loop whose solve streams through a workspace (T = 30 beyond the chip-resident batch):
+    captured on the library's fixed workspace when it fits (2,000 vehicles: 27 MB of 64 MiB), and
+    then equal to the eager loop bit for bit; refused up front when it does not (6,000: 81 MB; the
+    growing workspace would be allocated and waited for inside the capture), after which the loop
+    still runs eagerly."""
     from model_predictive_control_amd import _lib
     engine, v, ov, table, tabs, state, cid, pind = _setup("dsr_ackermann", 2000, 33, T=30)
+    eager = engine.ClosedLoop(v, table, state, cid, pind0=pind).run(6)
+    graph = engine.ClosedLoop(v, table, state, cid, pind0=pind).capture()
+    graph.run(4)
+    torch.cuda.synchronize()
+    assert graph.n_done_ticks == eager.n_done_ticks == 6
+    for name in ("state", "target_ind", "done", "ticks", "has_prev"):
+        np.testing.assert_array_equal(getattr(graph, name).cpu().numpy(), getattr(eager, name).cpu().numpy())
+    np.testing.assert_array_equal(graph.last_u.cpu().numpy(), eager.last_u.cpu().numpy())
+    assert (graph.out["status"].cpu().numpy() <= 1).mean() > 0.99
+
+    engine, v, ov, table, tabs, state, cid, pind = _setup("dsr_ackermann", 6000, 33, T=30)
     loop = engine.ClosedLoop(v, table, state, cid, pind0=pind)
     with pytest.raises(_lib.MpcxError, match="workspace"):
         loop.capture()
-    loop.run(1)
+    loop.run(2)
     torch.cuda.synchronize()
-    # the refused capture left the loop usable: the tick after it solves as usual
-    assert (loop.uprev.abs().sum() > 0)
-    loop.run(1)
-    torch.cuda.synchronize()
-    assert (loop.uprev.abs().sum() > 0) and int((loop.ticks == 2).sum().item()) == 2000
+    assert int((loop.ticks == 2).sum().item()) == 6000
+    assert (loop.out["status"].cpu().numpy() <= 1).mean() > 0.99 and float(loop.uprev.abs().sum().item()) > 0

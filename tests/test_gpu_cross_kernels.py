@@ -1,7 +1,8 @@
 """Independent kernels for the same problem agree with each other: the lane-pair kernel and the
 one-lane-per-instance dense kernel at T = 5, the wavefront-per-instance kernel and the stage-wise
-kernel at T = 12 and 20, all three kernels that take T = 10.  The routing hooks are read when the library loads, so each alternative runs
-in a child process."""
+kernel at T = 12 and 20, all three kernels that take T = 10.  The routing hooks (and the
+one-lane-per-instance kernel) exist only in the test build of the library, libmpcx_hooks.so,
+which reads them when it loads: each alternative runs in a child process that loads that build."""
 import os
 import subprocess
 import sys
@@ -30,7 +31,9 @@ np.savez(path, u=out["u"].cpu().numpy(), obj=out["obj"].cpu().numpy(), status=ou
 
 
 def _run(env_extra, name, B, T, path):
-    env = dict(os.environ, **env_extra)
+    hooks_lib = os.path.join(ROOT, "model_predictive_control_amd", "lib", "libmpcx_hooks.so")
+    assert os.path.exists(hooks_lib), "build the test-hook library: python -m model_predictive_control_amd.build"
+    env = dict(os.environ, MPCX_LIB=hooks_lib, **env_extra)
     subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT), name, str(B), str(T), path], check=True, env=env,
                    timeout=300)
     return np.load(path)

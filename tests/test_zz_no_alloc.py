@@ -81,3 +81,65 @@ def test_noalloc_entry_point_matches_the_allocating_one():
 
 def _lib_E_NOMEM():
     return -4
+
+
+def test_noalloc_call_inside_a_graph_and_free_memory_stands_still():
+    """After the documented set-up (mpcx_static_workspace_bytes() on the device, one warm-up call),
+    the call can be recorded into a HIP graph and replayed bit-identically, and the device's
+    free memory (hipMemGetInfo) is the same before and after a run of further calls."""
+    from model_predictive_control_amd import _lib
+    lib = _lib.load()
+    lib.mpcx_static_workspace_bytes()
+    v, ov, x0, xref = make_problem("dsr_ackermann", 1500, seed=94, T=30)
+    assert lib.mpcx_workspace_bytes(C.byref(v), 1500) > 0
+    d_x0, d_xref = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
+    rc, want = _call(lib.mpcx_solve_batch_noalloc, v, d_x0, d_xref, None)       # warm-up call
+    assert rc == 0 and (want["status"] == 0).all()
+    B, T, NU = 1500, v.T, v.nu
+    out = dict(u=torch.zeros((B, NU, T), dtype=torch.float64, device="cuda"),
+               x=torch.zeros((B, 3, T + 1), dtype=torch.float64, device="cuda"),
+               obj=torch.zeros((B,), dtype=torch.float64, device="cuda"),
+               status=torch.zeros((B,), dtype=torch.int32, device="cuda"),
+               iters=torch.zeros((B,), dtype=torch.int32, device="cuda"))
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def launch():
+        rc = lib.mpcx_solve_batch_noalloc(C.byref(v), B, p(d_x0), p(d_xref), None, None, p(out["u"]), p(out["x"]),
+                                          p(out["obj"]), p(out["status"]), p(out["iters"]),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.mpcx_last_error()
+
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, (free0, free1)
+    for k in want:
+        assert np.array_equal(out[k].cpu().numpy(), want[k]), k
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        launch()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        launch()
+    for t in out.values():
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for k in want:
+        assert np.array_equal(out[k].cpu().numpy(), want[k]), k
+    free2, _ = torch.cuda.mem_get_info()
+    for t in out.values():
+        t.zero_()
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    free3, _ = torch.cuda.mem_get_info()
+    assert free3 == free2, (free2, free3)
+    for k in want:
+        assert np.array_equal(out[k].cpu().numpy(), want[k]), k

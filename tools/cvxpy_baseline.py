@@ -76,12 +76,13 @@ def run(variant: str, x0, xref, uprev=None, has_prev=None, n_solves: int = 200):
     solver = cp.ECOS if "ECOS" in cp.installed_solvers() else None
     n = min(n_solves, x0.shape[0])
     cold = np.tile(np.asarray(v.cold_start, dtype=float)[:v.nu, None], (1, v.T))
-    worst, solved = 0.0, 0
-    t0 = time.perf_counter()
+    worst, solved, dt = 0.0, 0, 0.0
     for b in range(n):
         warm = uprev is not None and (has_prev is None or has_prev[b])
         uref = np.asarray(uprev[b], dtype=float) if warm else cold
-        u = solve_one(cp, v, O, xref[b], x0[b], uref, solver)
+        t0 = time.perf_counter()
+        u = solve_one(cp, v, O, xref[b], x0[b], uref, solver)     # problem construction + solve, as the reference does per call
+        dt += time.perf_counter() - t0
         if u is None:
             continue
         solved += 1
@@ -89,10 +90,9 @@ def run(variant: str, x0, xref, uprev=None, has_prev=None, n_solves: int = 200):
             ref = O.iterative_linear_mpc_control(v, xref[b], x0[b], uref if warm else None)
             if ref.u is not None:
                 worst = max(worst, float(np.abs(ref.u - u).max()))
-    dt = time.perf_counter() - t0      # includes the oracle's check solve: an upper bound on the cvxpy time
     return {"value": n / dt, "unit": "solves/s", "cores": 1, "solves": n, "solved": solved, "seconds": dt,
             "solver": "ECOS" if solver else "cvxpy default", "max_abs_du_vs_oracle": worst,
-            "note": "problem rebuilt per call like the reference; time includes a check solve by the numpy oracle"}
+            "note": "problem rebuilt per call like the reference; only the cvxpy construction + solve is timed (the check against the oracle is not)"}
 
 
 if __name__ == "__main__":
