@@ -108,6 +108,17 @@ int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const d
                      const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,
                      double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream);
 
+/* mpcx_solve_batch over the instances range[0] .. range[1]-1 only, the two bounds read from
+ * DEVICE memory when the kernel runs (the rest of the batch is neither read nor written): for a
+ * fleet sorted by motion mode on the device, where MPC.iterativeLMPC's dispatch
+ * `if mode == 'ackermann' ... elif mode == 'diff' ... elif mode == 'crab'` (mpc_sim.py:301-306)
+ * becomes one call per mode over its run of the sorted batch, without the host ever learning
+ * where the runs begin.  T = 5 with every bound present (the lane-pair kernel); MPCX_E_UNSUPPORTED
+ * otherwise. */
+int mpcx_solve_range_batch(const mpcx_variant *v, int64_t B, const int32_t *range, const double *x0, const double *xref,
+                           const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,
+                           double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream);
+
 /* No counterpart in the reference: mpcx_solve_batch for callers that cannot allocate device
  * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
  * Same arguments, same kernels, same results; the call itself allocates and frees nothing,
@@ -182,6 +193,21 @@ int mpcx_advance_batch(const mpcx_variant *v, int64_t B, double goal_dis, double
                        const double *cx, const double *cy, const int32_t *clen, int64_t n_courses, int64_t Lmax,
                        double *state, double *twist, uint8_t *has_prev, uint8_t *done, int32_t *ticks,
                        double *log_out, void *stream);
+
+/* What MPC.doSimulationWithAllMotionModes (mpc_sim.py:254-265) does between two ticks for vehicles
+ * whose course is a list of segments (rows seg_start[b] .. seg_start[b] + seg_count[b] - 1 of the
+ * course tables), after mpcx_advance_batch: for the vehicles with was_active[b] != 0 (done == 0 and
+ * not finished when the tick began) the tick is counted against the segment (seg_ticks); done == 2
+ * (reference window lost) finishes the vehicle; done == 1 (goal of the segment) or seg_ticks ==
+ * max_ticks_per_segment moves it to its next segment, or finishes it (done = 1) after the last.
+ * Entering a segment is doSimulation's prologue (mpc_sim.py:204-222): course_id = the new row, yaw
+ * moved by 2 pi towards the row's first yaw, has_prev = 0, done = 0, seg_ticks = 0, and enter[b] = 1
+ * with pind_next[b] = 0 so that the caller's next mpcx_nearest_ref_batch call (pind = pind_next)
+ * searches from the segment's start; for every other vehicle enter[b] = 0, pind_next[b] = target_ind[b]. */
+int mpcx_segment_step_batch(int64_t B, int32_t max_ticks_per_segment, const uint8_t *was_active, const int32_t *seg_start,
+                            const int32_t *seg_count, int32_t *seg, int32_t *seg_ticks, uint8_t *finished, uint8_t *done,
+                            uint8_t *has_prev, int32_t *course_id, double *state, const double *cyaw, int64_t n_courses,
+                            int64_t Lmax, const int32_t *target_ind, int32_t *pind_next, uint8_t *enter, void *stream);
 
 /* calc_spline_course (cubic_spline_planner.py:311-323: CubicSpline2D :174-308 over two
  * CubicSpline1D :12-171) for K courses at once, optionally followed by smooth_yaw

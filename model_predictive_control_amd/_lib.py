@@ -15,6 +15,7 @@ ST_OK, ST_INACCURATE, ST_INFEASIBLE, ST_NONFINITE, ST_FAILED = 0, 1, 2, 3, 4
 MODEL_DIFF_DRIVE, MODEL_DSR = 0, 1
 EQ_NONE, EQ_ACKERMANN, EQ_CRAB, EQ_FIXED_STEER = 0, 1, 2, 3
 MAX_T = 64
+E_ARG, E_UNSUPPORTED, E_HIP, E_NOMEM = -1, -2, -3, -4
 
 
 class MpcxError(RuntimeError):
@@ -46,6 +47,9 @@ SIGNATURES = {
     "mpcx_solve_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
     "mpcx_solve_batch_noalloc": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
     "mpcx_static_workspace_bytes": (C.c_int64, []),
+    "mpcx_solve_range_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
+    "mpcx_segment_step_batch": (C.c_int, [C.c_int64, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD,
+                                          C.c_int64, C.c_int64, _PD, _PD, _PD, _PD]),
     "mpcx_linear_mpc_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
     "mpcx_rollout_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD]),
     "mpcx_linearize_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD]),

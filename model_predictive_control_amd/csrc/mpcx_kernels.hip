@@ -47,6 +47,7 @@ struct SolveArgs {
     int32_t *status_out, *iters_out;
     int32_t linear_mode;   // 1: (xbar, uref) given -> one QP;  0: cold start + rollout (+ chain)
     int32_t max_iter;
+    const int32_t *range;  // device memory, {first, end}: only these instances are solved (nullptr: all)
 };
 
 // STORED: the linearisation point lives in the store (chained mpc_sim solves, and the
@@ -1025,6 +1026,58 @@ __global__ __launch_bounds__(256) void k_advance(mpcx_variant v, int64_t B, doub
     }
 }
 
+// What MPC.doSimulationWithAllMotionModes (mpc_sim.py:254-265) does between two ticks of a vehicle
+// whose course is a list of segments, and what doSimulation does before its loop for the segment
+// entered (mpc_sim.py:204-222): count the tick against the segment's budget; a lost reference
+// window ends the run; a goal reached or a spent budget moves on to the next segment (state kept,
+// warm start dropped, initial yaw compensation against the new segment's first yaw, nearest index
+// to be searched from the segment's start: enter = 1) or, after the last one, ends the run.
+__global__ __launch_bounds__(256) void k_segment_step(int64_t B, int cap, const uint8_t *__restrict__ was_active,
+                                                      const int32_t *__restrict__ seg_start,
+                                                      const int32_t *__restrict__ seg_count, int32_t *__restrict__ seg,
+                                                      int32_t *__restrict__ seg_ticks, uint8_t *__restrict__ finished,
+                                                      uint8_t *__restrict__ done, uint8_t *__restrict__ has_prev,
+                                                      int32_t *__restrict__ course_id, double *__restrict__ state,
+                                                      const double *__restrict__ cyaw, int64_t n_courses, int64_t Lmax,
+                                                      const int32_t *__restrict__ target_ind, int32_t *__restrict__ pind_next,
+                                                      uint8_t *__restrict__ enter)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    bool go = false;
+    if (was_active[b]) {
+        const int nt = seg_ticks[b] + 1;
+        seg_ticks[b] = nt;
+        const int d = done[b];
+        if (d == 2) {
+            finished[b] = 1;
+        } else if (d == 1 || nt >= cap) {
+            const int sn = seg[b] + 1;
+            seg[b] = sn;
+            if (sn >= seg_count[b]) {
+                finished[b] = 1;
+                done[b] = 1;
+            } else {
+                go = true;
+                const int64_t course = (int64_t)seg_start[b] + sn;
+                course_id[b] = (int32_t)course;
+                if (course >= 0 && course < n_courses) {   // rows outside the table: an empty window, never an index
+                    const double yaw = state[4 * b + 2];
+                    const double dy = yaw - cyaw[course * Lmax];
+                    const double two_pi = 2.0 * 3.141592653589793;
+                    if (dy >= 3.141592653589793) state[4 * b + 2] = yaw - two_pi;
+                    else if (dy <= -3.141592653589793) state[4 * b + 2] = yaw + two_pi;
+                }
+                has_prev[b] = 0;
+                done[b] = 0;
+                seg_ticks[b] = 0;
+            }
+        }
+    }
+    enter[b] = go ? 1 : 0;
+    pind_next[b] = go ? 0 : target_ind[b];
+}
+
 // ------------------------------------------------------------------------------------
 constexpr int kGroup = 16;
 
@@ -1320,6 +1373,8 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
     const dim3 block(kWave);
     clear_stale_error();
     const int m = v->model == MPCX_MODEL_DIFF_DRIVE ? 0 : 1;
+    if (a.range && choose_path(v, a.B, chained) != kPathPair5)
+        return fail(MPCX_E_UNSUPPORTED, "a device-resident instance range is taken by the T = 5 lane-pair kernel only");
     switch (choose_path(v, a.B, chained)) {
     case kPathPair5: {
         const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
@@ -1518,6 +1573,44 @@ int mpcx_solve_batch(const mpcx_variant *v, int64_t B, const double *x0, const d
 // Also the set-up call of mpcx_solve_batch_noalloc for the current device: the address of that
 // device's copy of the array is looked up here (loading the code object on the device if this
 // is the library's first use of it), so that the solve call itself does no lookup.
+int mpcx_solve_range_batch(const mpcx_variant *v, int64_t B, const int32_t *range, const double *x0, const double *xref,
+                           const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,
+                           double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream)
+{
+    int rc = check_variant(v);
+    if (rc) return rc;
+    if (B < 0 || B > 2147483647LL) return fail(MPCX_E_ARG, "batch outside 0..2^31-1");
+    if (!range) return fail(MPCX_E_ARG, "range is NULL");
+    if (B > 0 && (!x0 || !xref || !u_out || !x_out || !obj_out || !status_out))
+        return fail(MPCX_E_ARG, "NULL buffer");
+    SolveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.v = *v; a.B = B; a.x0 = x0; a.xref = xref; a.xbar = nullptr; a.uin = uprev; a.has_prev = has_prev;
+    a.u_out = u_out; a.x_out = x_out; a.obj_out = obj_out; a.status_out = status_out; a.iters_out = iters_out;
+    a.linear_mode = 0;
+    a.max_iter = 60;
+    a.range = range;
+    return launch_solve(a, (hipStream_t)stream);
+}
+
+int mpcx_segment_step_batch(int64_t B, int32_t max_ticks_per_segment, const uint8_t *was_active, const int32_t *seg_start,
+                            const int32_t *seg_count, int32_t *seg, int32_t *seg_ticks, uint8_t *finished, uint8_t *done,
+                            uint8_t *has_prev, int32_t *course_id, double *state, const double *cyaw, int64_t n_courses,
+                            int64_t Lmax, const int32_t *target_ind, int32_t *pind_next, uint8_t *enter, void *stream)
+{
+    if (B < 0 || n_courses < 1 || Lmax < 1 || max_ticks_per_segment < 1) return fail(MPCX_E_ARG, "bad sizes");
+    if (B == 0) return 0;
+    if (!was_active || !seg_start || !seg_count || !seg || !seg_ticks || !finished || !done || !has_prev || !course_id ||
+        !state || !cyaw || !target_ind || !pind_next || !enter)
+        return fail(MPCX_E_ARG, "NULL buffer");
+    clear_stale_error();
+    hipLaunchKernelGGL(k_segment_step, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B,
+                       (int)max_ticks_per_segment, was_active, seg_start, seg_count, seg, seg_ticks, finished, done, has_prev,
+                       course_id, state, cyaw, n_courses, Lmax, target_ind, pind_next, enter);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "k_segment_step launch");
+}
+
 int64_t mpcx_static_workspace_bytes(void)
 {
     int dev = 0;

@@ -598,7 +598,7 @@ struct StageIn {
     }
 };
 template <int MAXN, int PER>
-__device__ __forceinline__ void stage_out(double *__restrict__ g, int n, const lds_double *src, int lane)
+__device__ __forceinline__ void stage_out(double *__restrict__ g, int n0, int n, const lds_double *src, int lane)
 {
     constexpr int K = (MAXN + kWave - 1) / kWave;
     double tmp[K];
@@ -611,7 +611,7 @@ __device__ __forceinline__ void stage_out(double *__restrict__ g, int n, const l
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int i = lane + k * kWave;
-        if (i < n) g[i] = tmp[k];
+        if (i >= n0 && i < n) g[i] = tmp[k];
     }
 }
 

@@ -30,9 +30,17 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
     MPCX_STAMP(0);
     s.bind((MPCX_PAIR_NS::lds_double *)Hs, (MPCX_PAIR_NS::lds_double *)(kAliasDyn ? Hs : Ds), lane);
     const int64_t b0 = (int64_t)blockIdx.x * MPCX_PAIR_NS::kPairs;
-    const int nb = a.B - b0 < MPCX_PAIR_NS::kPairs ? (int)(a.B - b0) : MPCX_PAIR_NS::kPairs;
+    // the wave's records [first, nb) are solved: all that exist, or those inside the caller's range
+    int64_t r_lo = 0, r_hi = a.B;
+    if (a.range) {
+        r_lo = a.range[0] > 0 ? a.range[0] : 0;
+        r_hi = a.range[1] < a.B ? a.range[1] : a.B;
+        if (b0 + MPCX_PAIR_NS::kPairs <= r_lo || b0 >= r_hi) return;   // wave-uniform
+    }
+    const int nb = r_hi - b0 < MPCX_PAIR_NS::kPairs ? (int)(r_hi - b0) : MPCX_PAIR_NS::kPairs;
+    const int first = r_lo > b0 ? (int)(r_lo - b0) : 0;
     const int pl = lane >> 1;
-    const bool live = pl < nb;
+    const bool live = pl >= first && pl < nb;
     const int pc = live ? pl : nb - 1;   // idle pairs redo the wave's last instance so votes stay uniform
     const int64_t b = b0 + pc;
 
@@ -247,9 +255,9 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
     if (st_x) ((volatile MPCX_PAIR_NS::lds_double *)stg)[kOutJ + pl] = bad ? nan : J;
     MPCX_STAMP(12);
     __builtin_amdgcn_wave_barrier();
-    MPCX_PAIR_NS::stage_out<MPCX_PAIR_NS::kPairs * NU * T, NU * T>(a.u_out + b0 * NU * T, nb * NU * T, stg + kOutU, lane);
-    MPCX_PAIR_NS::stage_out<MPCX_PAIR_NS::kPairs * 3 * W, 3 * W>(a.x_out + b0 * 3 * W, nb * 3 * W, stg + kOutX, lane);
-    if (lane < nb) a.obj_out[b0 + lane] = ((const volatile MPCX_PAIR_NS::lds_double *)stg)[kOutJ + lane];
+    MPCX_PAIR_NS::stage_out<MPCX_PAIR_NS::kPairs * NU * T, NU * T>(a.u_out + b0 * NU * T, first * NU * T, nb * NU * T, stg + kOutU, lane);
+    MPCX_PAIR_NS::stage_out<MPCX_PAIR_NS::kPairs * 3 * W, 3 * W>(a.x_out + b0 * 3 * W, first * 3 * W, nb * 3 * W, stg + kOutX, lane);
+    if (lane >= first && lane < nb) a.obj_out[b0 + lane] = ((const volatile MPCX_PAIR_NS::lds_double *)stg)[kOutJ + lane];
     if (live && !s.odd) {
         a.status_out[b] = status;
         if (a.iters_out) a.iters_out[b] = iters;

@@ -371,7 +371,17 @@ class SegmentedLoop:
 
     variants[m]: the solver variant of mode m (same model, horizon and dt for all);
     seg_mode [K]: mode index of every table row;  seg_start [B], seg_count [B]: each vehicle's rows
-    (consecutive).  Per tick the solves are launched per mode on the vehicles currently in it."""
+    (consecutive).
+
+    A tick never waits for the device (no host round trip, every launch on the current stream):
+    reference windows for the whole fleet; the vehicles sorted by the mode they are in (a stable
+    device sort; vehicles at rest last) and their solve inputs gathered in that order; one solve
+    per mode over its run of the sorted batch, the run's bounds staying in device memory
+    (mpcx_solve_range_batch); controls and statuses scattered back; state advance and goal test;
+    segment hand-over (mpcx_segment_step_batch) and the first nearest index of the vehicles that
+    entered a segment.  That needs solves the T = 5 lane-pair kernel takes (every mpc_sim mode
+    does); other variant sets fall back to one compacted launch per mode with the host reading
+    the index lists (`self.device_resident` tells which)."""
 
     def __init__(self, variants, table: CourseTable, seg_mode, seg_start, seg_count, state, max_ticks_per_segment: int,
                  goal_dis: float = 1.5, stop_speed: float = 0.2, n_search_ind: int = 2, n_search: int = 10,
@@ -384,19 +394,20 @@ class SegmentedLoop:
         self.state = _dev(state).clone()
         B = self.B = self.state.shape[0]
         dev = self.state.device
+        M = len(self.variants)
         self.seg_mode = _dev(seg_mode, torch.int64)
-        self.seg_start = _dev(seg_start, torch.int64)
-        self.seg_count = _dev(seg_count, torch.int64)
+        self.seg_start = _dev(seg_start, torch.int32)
+        self.seg_count = _dev(seg_count, torch.int32)
         self.cap = int(max_ticks_per_segment)
         self.goal_dis, self.stop_speed = float(goal_dis), float(stop_speed)
         self.n_search_ind, self.n_search = int(n_search_ind), int(n_search)
-        self.seg = torch.zeros(B, dtype=torch.int64, device=dev)
-        self.seg_ticks = torch.zeros(B, dtype=torch.int64, device=dev)
-        self.finished = self.seg_count <= 0
+        self.seg = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.seg_ticks = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.finished = (self.seg_count <= 0).to(torch.uint8)
         self.course_id = (self.seg_start + self.seg).to(torch.int32)
         self.twist = torch.zeros((B, 2), dtype=torch.float64, device=dev)
         self.has_prev = torch.zeros(B, dtype=torch.uint8, device=dev)
-        self.done = self.finished.to(torch.uint8)
+        self.done = self.finished.clone()
         self.ticks = torch.zeros(B, dtype=torch.int32, device=dev)
         self.target_ind = torch.zeros(B, dtype=torch.int32, device=dev)
         self.xref = torch.empty((B, 3, v0.T + 1), dtype=torch.float64, device=dev)
@@ -406,14 +417,36 @@ class SegmentedLoop:
         self.uprev = torch.zeros((B, v0.nu, v0.T), dtype=torch.float64, device=dev)
         self.log = torch.empty((log_ticks + 1, B, 4), dtype=torch.float64, device=dev) if log_ticks else None
         self.n_done_ticks = 0
-        self._enter_segment(torch.nonzero(~self.finished).flatten())
+        # buffers of the device-resident tick
+        self._sorted = _outputs(B, v0.nu, v0.T, dev)
+        self._pind_next = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._enter = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self._ind_tmp = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._mode_ids = torch.arange(M + 1, dtype=torch.int64, device=dev)
+        self._rest = torch.full((B,), M, dtype=torch.int64, device=dev)
+        self.device_resident = self._range_solve_available()
+        self._enter_segment(torch.nonzero(self.finished == 0).flatten())
         if self.log is not None:
             self.log[0].copy_(self.state)
+
+    def _range_solve_available(self) -> bool:
+        """Whether every mode's solve can be given a device-resident range (an empty one here)."""
+        o = self._sorted
+        empty = torch.zeros(2, dtype=torch.int32, device=self.state.device)
+        for v in self.variants:
+            rc = self.lib.mpcx_solve_range_batch(C.byref(v), self.B, _ptr(empty), _ptr(self.x0), _ptr(self.xref),
+                                                 _ptr(self.uprev), _ptr(self.has_prev), _ptr(o["u"]), _ptr(o["x"]),
+                                                 _ptr(o["obj"]), _ptr(o["status"]), _ptr(o["iters"]), _stream())
+            if rc == _lib.E_UNSUPPORTED:
+                return False
+            _lib.check(rc)
+        return True
 
     def _enter_segment(self, idx):
         """What doSimulation does before its loop (mpc_sim.py:204-222) for the vehicles `idx`
         entering their current segment: yaw compensation against the segment's first yaw, first
-        nearest index searched from the segment's start, cold start."""
+        nearest index searched from the segment's start, cold start.  (Set-up, and the ticks of the
+        fallback path; the device-resident tick does this in mpcx_segment_step_batch.)"""
         if idx.numel() == 0:
             return
         t = self.table
@@ -432,16 +465,66 @@ class SegmentedLoop:
         self.done[idx] = 0
         self.seg_ticks[idx] = 0
 
+    def _nearest(self, pind, ind_out, xref):
+        t, v0 = self.table, self.variants[0]
+        _lib.check(self.lib.mpcx_nearest_ref_batch(1, v0.T, v0.dt, float(self.n_search_ind), self.n_search, 1, self.B,
+                                                   _ptr(self.state), _ptr(self.course_id), _ptr(pind),
+                                                   _ptr(t.cx), _ptr(t.cy), _ptr(t.cyaw), _ptr(t.clen), t.K, t.Lmax,
+                                                   _ptr(ind_out), None, _ptr(xref), _stream()))
+
+    def _advance(self, k):
+        t, v0, o = self.table, self.variants[0], self.out
+        log = self.log[k] if self.log is not None and k < self.log.shape[0] else None
+        _lib.check(self.lib.mpcx_advance_batch(C.byref(v0), self.B, self.goal_dis, self.stop_speed, _ptr(o["u"]),
+                                               _ptr(o["status"]), _ptr(self.target_ind), _ptr(self.course_id),
+                                               _ptr(t.cx), _ptr(t.cy), _ptr(t.clen), t.K, t.Lmax, _ptr(self.state),
+                                               _ptr(self.twist), _ptr(self.has_prev), _ptr(self.done), _ptr(self.ticks),
+                                               _ptr(log), _stream()))
+
     def tick(self):
-        t, v0, lib, st = self.table, self.variants[0], self.lib, _stream()
-        _lib.check(lib.mpcx_nearest_ref_batch(1, v0.T, v0.dt, float(self.n_search_ind), self.n_search, 1, self.B,
-                                              _ptr(self.state), _ptr(self.course_id), _ptr(self.target_ind),
-                                              _ptr(t.cx), _ptr(t.cy), _ptr(t.cyaw), _ptr(t.clen), t.K, t.Lmax,
-                                              _ptr(self.target_ind), None, _ptr(self.xref), st))
+        if not self.device_resident:
+            return self._tick_with_host_lists()
+        t, lib, st, M = self.table, self.lib, _stream(), len(self.variants)
+        self._nearest(self.target_ind, self.target_ind, self.xref)
+        self.x0.copy_(self.state[:, :3])
+        active = (self.finished == 0) & (self.done == 0)
+        was_active = active.to(torch.uint8)
+        mode = self.seg_mode[self.course_id.long().clamp(0, t.K - 1)]
+        key = torch.where(active, mode, self._rest)                       # vehicles at rest sort last
+        skey, order = torch.sort(key, stable=True)
+        bounds = torch.searchsorted(skey, self._mode_ids).to(torch.int32)  # run of mode m: bounds[m] .. bounds[m + 1]
+        g_x0, g_xref = self.x0.index_select(0, order), self.xref.index_select(0, order)
+        g_up, g_hp = self.uprev.index_select(0, order), self.has_prev.index_select(0, order)
+        so = self._sorted
+        for m, v in enumerate(self.variants):
+            _lib.check(lib.mpcx_solve_range_batch(C.byref(v), self.B, C.c_void_p(bounds.data_ptr() + 4 * m), _ptr(g_x0),
+                                                  _ptr(g_xref), _ptr(g_up), _ptr(g_hp), _ptr(so["u"]), _ptr(so["x"]),
+                                                  _ptr(so["obj"]), _ptr(so["status"]), _ptr(so["iters"]), st))
+        o = self.out
+        # rows past the last run (vehicles at rest) carry stale values; the advance ignores them (done != 0)
+        o["u"].index_copy_(0, order, so["u"])
+        o["status"].index_copy_(0, order, so["status"])
+        k = self.n_done_ticks + 1
+        self._advance(k)
+        o["u"], self.uprev = self.uprev, o["u"]
+        self.n_done_ticks = k
+        _lib.check(lib.mpcx_segment_step_batch(self.B, self.cap, _ptr(was_active), _ptr(self.seg_start), _ptr(self.seg_count),
+                                               _ptr(self.seg), _ptr(self.seg_ticks), _ptr(self.finished), _ptr(self.done),
+                                               _ptr(self.has_prev), _ptr(self.course_id), _ptr(self.state), _ptr(t.cyaw),
+                                               t.K, t.Lmax, _ptr(self.target_ind), _ptr(self._pind_next), _ptr(self._enter), st))
+        # first nearest index of the vehicles that entered a segment, searched from its start
+        self._nearest(self._pind_next, self._ind_tmp, None)
+        self.target_ind.copy_(torch.where(self._enter != 0, self._ind_tmp, self.target_ind))
+        if self.log is not None and k < self.log.shape[0]:
+            self.log[k].copy_(self.state)     # after a possible yaw compensation of the next segment
+
+    def _tick_with_host_lists(self):
+        t = self.table
+        self._nearest(self.target_ind, self.target_ind, self.xref)
         self.x0.copy_(self.state[:, :3])
         o = self.out
         mode = self.seg_mode[self.course_id.long().clamp(0, t.K - 1)]
-        active = ~self.finished & (self.done == 0)
+        active = (self.finished == 0) & (self.done == 0)
         for m, v in enumerate(self.variants):
             idx = torch.nonzero(active & (mode == m)).flatten()
             if idx.numel() == 0:
@@ -450,24 +533,19 @@ class SegmentedLoop:
             o["u"][idx] = part["u"]
             o["status"][idx] = part["status"]
         k = self.n_done_ticks + 1
-        log = self.log[k] if self.log is not None and k < self.log.shape[0] else None
-        _lib.check(lib.mpcx_advance_batch(C.byref(v0), self.B, self.goal_dis, self.stop_speed, _ptr(o["u"]),
-                                          _ptr(o["status"]), _ptr(self.target_ind), _ptr(self.course_id),
-                                          _ptr(t.cx), _ptr(t.cy), _ptr(t.clen), t.K, t.Lmax, _ptr(self.state),
-                                          _ptr(self.twist), _ptr(self.has_prev), _ptr(self.done), _ptr(self.ticks),
-                                          _ptr(log), st))
+        self._advance(k)
         o["u"], self.uprev = self.uprev, o["u"]
         self.n_done_ticks = k
         # segment bookkeeping: goal reached or the segment's ticks spent -> next segment; a lost
         # reference window (where the reference raises) ends the vehicle's run
-        self.seg_ticks += active.long()
+        self.seg_ticks += active.to(torch.int32)
         lost = active & (self.done == 2)
         move = active & ~lost & ((self.done == 1) | (self.seg_ticks >= self.cap))
-        self.finished |= lost
+        self.finished |= lost.to(torch.uint8)
         if bool(move.any().item()):
-            self.seg += move.long()
+            self.seg += move.to(torch.int32)
             ended = move & (self.seg >= self.seg_count)
-            self.finished |= ended
+            self.finished |= ended.to(torch.uint8)
             go = move & ~ended
             self.course_id = torch.where(go, (self.seg_start + self.seg).to(torch.int32), self.course_id)
             self.done = torch.where(ended, torch.ones_like(self.done), self.done)
@@ -475,9 +553,11 @@ class SegmentedLoop:
         if self.log is not None and k < self.log.shape[0]:
             self.log[k].copy_(self.state)     # after a possible yaw compensation of the next segment
 
-    def run(self, n_ticks: int):
+    def run(self, n_ticks: int, until_finished: bool = False):
+        """n_ticks ticks; a tick is a no-op for vehicles that have finished.  `until_finished`
+        looks at the fleet's flags before every tick (one host round trip each) and stops early."""
         for _ in range(n_ticks):
-            if bool(self.finished.all().item()):
+            if until_finished and bool((self.finished != 0).all().item()):
                 break
             self.tick()
         return self

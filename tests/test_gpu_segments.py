@@ -42,7 +42,13 @@ def test_fleet_on_mixed_mode_courses_matches_the_oracle_segment_by_segment():
     ctl = mpc_sim.MPC()
     loop = engine.SegmentedLoop(ctl.segment_variants(), table, seg_mode, seg_start, seg_count, state, cap,
                                 goal_dis=ctl.xy_tolerance_, stop_speed=ctl.stop_speed_, log_ticks=3 * cap)
-    loop.run(3 * cap + 2)
+    assert loop.device_resident
+    # the ticks must not wait for the device anywhere: any synchronising call raises here
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loop.run(3 * cap + 2)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
     torch.cuda.synchronize()
     assert bool(loop.finished.all().item())
     tabs = (table.cx.cpu().numpy(), table.cy.cpu().numpy(), table.cyaw.cpu().numpy(), table.clen_host)
@@ -111,7 +117,7 @@ def test_segmented_loop_edge_cases():
     loop = engine.SegmentedLoop(ctl.segment_variants(), table, [0, 1, 2], seg_start, seg_count, state, 4,
                                 goal_dis=ctl.xy_tolerance_, stop_speed=ctl.stop_speed_, log_ticks=8)
     fin0 = loop.finished.cpu().numpy()
-    assert fin0.tolist() == [False, True, False, False]
+    assert fin0.astype(bool).tolist() == [False, True, False, False]
     loop.run(8)
     torch.cuda.synchronize()
     assert bool(loop.finished.all().item())
@@ -125,3 +131,35 @@ def test_segmented_loop_edge_cases():
     with pytest.raises(ValueError):
         engine.SegmentedLoop([variants.get("sim_ackermann"), variants.get("sim_crab", T=8)], table, [0, 1, 0],
                              seg_start[:1], seg_count[:1], state[:1], 4)
+
+
+def test_device_resident_ticks_equal_the_host_list_ticks():
+    """The device-resident tick (sorted fleet, one ranged solve per mode) and the fallback that
+    compacts index lists on the host produce the same fleet, bit for bit."""
+    from model_predictive_control_amd import engine, mpc_sim, workload
+    courses = workload.make_courses(5, seed=77)
+    rows, seg_mode = [], []
+    for k, (cx, cy, cyaw) in enumerate(courses):
+        h = len(cx) // 2
+        for s, (a, b) in enumerate(((0, h), (h, len(cx)))):
+            rows.append((cx[a:b], cy[a:b], np.array(O.smooth_yaw(list(cyaw[a:b])))))
+            seg_mode.append((k + 2 * s) % 3)
+    table = engine.CourseTable(rows)
+    B = 333                                   # runs that end inside a wavefront of 32 instances
+    rng = np.random.default_rng(9)
+    cid = rng.integers(0, len(courses), B)
+    seg_start, seg_count = 2 * cid, rng.integers(0, 3, B)
+    state = np.array([[rows[r][0][0] + rng.normal(0, 0.1), rows[r][1][0] + rng.normal(0, 0.1), rows[r][2][0], 0.0] for r in seg_start])
+    ctl = mpc_sim.MPC()
+    loops = []
+    for resident in (True, False):
+        lp = engine.SegmentedLoop(ctl.segment_variants(), table, seg_mode, seg_start, seg_count, state, 3,
+                                  goal_dis=ctl.xy_tolerance_, stop_speed=ctl.stop_speed_, log_ticks=7)
+        assert lp.device_resident
+        lp.device_resident = resident
+        lp.run(7)
+        loops.append(lp)
+    torch.cuda.synchronize()
+    a, b = loops
+    for name in ("state", "ticks", "done", "finished", "seg", "target_ind", "course_id", "has_prev", "log"):
+        np.testing.assert_array_equal(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy(), err_msg=name)
