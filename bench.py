@@ -192,7 +192,8 @@ def other_configs(steps: int = 3):
     for name, B, T, kernel in (("diff_drive", 65536, None, "k_solve_pair5<diff-drive>"),
                                ("diff_drive", 262144, None, "k_solve_pair5<diff-drive>"),
                                ("sim_ackermann", 65536, None, "k_solve_pair5<dual-steer, chain of 5 QPs> (MPC.iterativeLMPC, mpc_sim.py:284-310)"),
-                               ("mpc_py", 65536, None, "k_solve_stage<dual-steer>"),
+                               ("mpc_py", 65536, None, "k_solve_quad<dual-steer, T=10> (four lanes per instance)"),
+                               ("mpc_py", 32768, None, "k_solve_quad<dual-steer, T=10> (four lanes per instance)"),
                                ("dsr_diff", 65536, 30, "k_solve_stage<dual-steer>"),
                                ("dsr_ackermann", 65536, 30, "k_solve_stage<dual-steer>")):
         v = variants.get(name, T=T) if T else variants.get(name)
@@ -206,7 +207,7 @@ def other_configs(steps: int = 3):
         for start, u in (("cold", None), ("warm", up)):
             if start == "cold" and T != 30:
                 continue
-            n = steps if v.T > 5 else 40 * steps      # the short kernels need more launches for a stable figure
+            n = steps if v.T > 10 else 40 * steps      # the short kernels need more launches for a stable figure
             for _ in range(max(1, n // 4)):
                 engine.solve_batch(v, d_x0, d_xref, u, out=out)
             torch.cuda.synchronize()

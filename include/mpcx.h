@@ -87,8 +87,8 @@ const char *mpcx_last_error(void);
 int mpcx_variant_by_name(const char *name, mpcx_variant *out);
 
 /* Bytes of device workspace mpcx_solve_batch / mpcx_linear_mpc_batch need for B
- * instances of this variant: 0 for the kernels that live in registers and LDS (T = 5,
- * T = 10 up to 32,768 instances, and batches up to T = 32 that the chip holds at once),
+ * instances of this variant: 0 for the kernels that live in registers and LDS (T = 5 and
+ * T = 10 at every batch size, and batches up to T = 32 that the chip holds at once),
  * otherwise the per-lane
  * arrays of the stage-wise kernel for one launch (440 T bytes per instance, at most
  * 262,144 instances per launch).  The library keeps one grow-only buffer per device for

@@ -245,6 +245,8 @@ constexpr int kPairRounds1 = 4;              // ... and after a converged interi
 #undef MPCX_PAIR_NS
 #undef MPCX_PAIR_KERNEL
 
+// the lane-pair layout at T = 10 (superseded by four lanes per instance): test-hook library only
+#ifdef MPCX_TEST_HOOKS
 #define MPCX_PAIR_TT 10
 #define MPCX_PAIR_NS pair10
 #define MPCX_PAIR_KERNEL k_solve_pair10
@@ -253,6 +255,10 @@ constexpr int kPairRounds1 = 4;              // ... and after a converged interi
 #undef MPCX_PAIR_TT
 #undef MPCX_PAIR_NS
 #undef MPCX_PAIR_KERNEL
+#endif
+
+#include "mpcx_quad.h"
+#include "mpcx_quad_kernel.h"
 
 namespace mpcx {
 
@@ -1253,9 +1259,12 @@ static bool boxes_present(const mpcx_variant *v)
 #ifdef MPCX_TEST_HOOKS
 static const bool g_force_single_lane = [] { const char *e = getenv("MPCX_SINGLE_LANE"); return e && e[0] == '1'; }();
 static const int g_stagewise = [] { const char *e = getenv("MPCX_STAGEWISE"); return e ? atoi(e) : -1; }();
+// MPCX_T10=pair routes T = 10 to the lane-pair kernel (up to its batch limit), =quad to the four-lane kernel
+static const int g_t10 = [] { const char *e = getenv("MPCX_T10"); return !e ? 0 : (!strcmp(e, "pair") ? 1 : (!strcmp(e, "quad") ? 2 : 0)); }();
 #else
 constexpr bool g_force_single_lane = false;
 constexpr int g_stagewise = -1;
+constexpr int g_t10 = 0;
 #endif
 
 // grow-only per-device workspace of the stage-wise kernel
@@ -1286,29 +1295,29 @@ static int64_t wave_batch_max(int T)
     return 256 * (by_lds < by_regs ? by_lds : by_regs);
 }
 
-enum SolvePath { kPathPair5, kPathReg5, kPathPair10, kPathWave, kPathStage };
+enum SolvePath { kPathPair5, kPathReg5, kPathPair10, kPathQuad10, kPathWave, kPathStage };
 
-// Largest batch the T = 10 lane-pair kernel is given.  The chip holds 16,384 of its instances at
-// once (70 KB of LDS per wavefront: two wavefronts per CU) and every further 16,384 cost the
-// same 0.37 ms again, while the stage-wise kernel streams at 5 TB/s from its first wavefront on:
-// measured on mpc.py's controller, warm, 32,768 instances take 0.76 ms against 0.82 ms, 65,536
-// take 1.47 ms against 1.15 ms.
+// Largest batch the T = 10 lane-pair kernel (test-hook library only) is given: it spills 1.6 KB per
+// lane and two of its wavefronts fill a CU's LDS, so the chip holds 16,384 instances at once.
 constexpr int64_t kPair10BatchMax = 32768;
 
-// T = 5 with every bound present: lane-pair kernel, chained or not.  Other horizons, unchained,
-// up to T = 32: batches that the chip holds at once go one wavefront per instance (lowest
-// latency: 64 lanes share one instance; T = 10: 0.18-0.21 ms against 0.27-0.29 ms for the lane
-// pairs).  T = 10 (mpc.py) with both boxes present: the T = 10 lane-pair kernel up to
-// kPair10BatchMax.  Everything else one lane per instance with stage-wise linear algebra (far
-// higher throughput once the chip is filled).
+// T = 5 with every bound present: lane-pair kernel, chained or not.  T = 10 (mpc.py) with both
+// boxes present, unchained: four lanes per instance at every batch size (one wavefront of 16
+// instances takes 0.10-0.12 ms, 65,536 instances 0.47 ms warm; the wavefront-per-instance kernel
+// needs 0.18-0.21 ms for what the chip holds at once, the stage-wise kernel 1.16 ms for 65,536).
+// Other horizons, unchained, up to T = 32: batches that the chip holds at once go one wavefront per
+// instance (lowest latency: 64 lanes share one instance).  Everything else one lane per instance
+// with stage-wise linear algebra (far higher throughput once the chip is filled).
 static SolvePath choose_path(const mpcx_variant *v, int64_t B, bool chained)
 {
     if (uses_registers(v)) return g_force_single_lane ? kPathReg5 : kPathPair5;
     const bool wave_fits = v->T <= 32 && !chained;
     if (g_stagewise == 1) return kPathStage;
     if (g_stagewise == 0 && wave_fits) return kPathWave;
+    const bool t10 = v->T == 10 && boxes_present(v) && !chained && !g_force_single_lane;
+    if (t10 && g_t10 == 1 && B <= kPair10BatchMax) return kPathPair10;
+    if (t10) return kPathQuad10;
     if (wave_fits && B <= wave_batch_max(v->T)) return kPathWave;
-    if (v->T == 10 && boxes_present(v) && !chained && !g_force_single_lane && B <= kPair10BatchMax) return kPathPair10;
     return kPathStage;
 }
 
@@ -1378,7 +1387,15 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
     switch (choose_path(v, a.B, chained)) {
     case kPathPair5: {
         const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
-        if (m == 0) {
+        if (a.range) {
+            if (m == 0) {
+                if (chained) hipLaunchKernelGGL((k_solve_pair5<0, true, true>), pgrid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_solve_pair5<0, false, true>), pgrid, block, 0, st, a);
+            } else {
+                if (chained) hipLaunchKernelGGL((k_solve_pair5<1, true, true>), pgrid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_solve_pair5<1, false, true>), pgrid, block, 0, st, a);
+            }
+        } else if (m == 0) {
             if (chained) hipLaunchKernelGGL((k_solve_pair5<0, true>), pgrid, block, 0, st, a);
             else hipLaunchKernelGGL((k_solve_pair5<0, false>), pgrid, block, 0, st, a);
         } else {
@@ -1407,11 +1424,23 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
 #endif
     }
     case kPathPair10: {
+#ifdef MPCX_TEST_HOOKS
         const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
         if (m == 0) hipLaunchKernelGGL((k_solve_pair10<0, false>), pgrid, block, 0, st, a);
         else hipLaunchKernelGGL((k_solve_pair10<1, false>), pgrid, block, 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_solve_pair10 launch");
+        return 0;
+#else
+        return fail(MPCX_E_UNSUPPORTED, "the T = 10 lane-pair kernel is part of the test-hook library only");
+#endif
+    }
+    case kPathQuad10: {
+        const dim3 qgrid((unsigned)((a.B + quad::kInst - 1) / quad::kInst));
+        if (m == 0) hipLaunchKernelGGL((k_solve_quad<0, 10>), qgrid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_solve_quad<1, 10>), qgrid, block, 0, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "k_solve_quad launch");
         return 0;
     }
     case kPathWave: {

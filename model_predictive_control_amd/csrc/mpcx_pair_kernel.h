@@ -4,7 +4,8 @@
 namespace mpcx {
 
 // CHAIN: the MPC.iterativeLMPC flavour (T chained QPs per call); otherwise exactly one QP.
-template <int MODEL, bool CHAIN>
+// RANGE: only the instances a.range[0] .. a.range[1]-1 (bounds in device memory) are solved.
+template <int MODEL, bool CHAIN, bool RANGE = false>
 __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveArgs a)
 {
     // LDS: Hs = input staging (x0, controls, xbar), then H and g, then output staging;
@@ -16,7 +17,7 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
     __shared__ double Hs[MPCX_PAIR_NS::kLdsPerLane * kWave];
     __shared__ double Ds[kAliasDyn ? 1 : MPCX_PAIR_NS::kDynDoubles * MPCX_PAIR_NS::kPairs];
     __shared__ double Xs[MPCX_PAIR_NS::kPairs * MPCX_PAIR_NS::padded(3 * (MPCX_PAIR_NS::TT + 1))];
-    __shared__ int Fs[kWave];
+    __shared__ int Fs[kWave + 2];   // per-instance input flags; the wave's record range
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
     constexpr int T = MPCX_PAIR_NS::TT, W = T + 1;
     constexpr int kFixedIters = T > 5 ? kPairIpmIters10 : kPairIpmIters;
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
     const int64_t b0 = (int64_t)blockIdx.x * MPCX_PAIR_NS::kPairs;
     // the wave's records [first, nb) are solved: all that exist, or those inside the caller's range
     int64_t r_lo = 0, r_hi = a.B;
-    if (a.range) {
+    if (RANGE) {
         r_lo = a.range[0] > 0 ? a.range[0] : 0;
         r_hi = a.range[1] < a.B ? a.range[1] : a.B;
         if (b0 + MPCX_PAIR_NS::kPairs <= r_lo || b0 >= r_hi) return;   // wave-uniform
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
     // and xbar; [32..63] controls (which only count for warm-started instances)
     volatile __attribute__((address_space(3))) int *flg = (volatile __attribute__((address_space(3))) int *)Fs;
     flg[lane] = 0;
+    if (RANGE && lane == 0) { flg[kWave] = first; flg[kWave + 1] = nb; }
     bool warm = false;
     auto stage_inputs = [&](bool with_xref) {
         MPCX_PAIR_NS::StageIn<MPCX_PAIR_NS::kPairs * 3 * W, 3 * W> in_xr, in_xb;
@@ -255,9 +257,12 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
     if (st_x) ((volatile MPCX_PAIR_NS::lds_double *)stg)[kOutJ + pl] = bad ? nan : J;
     MPCX_STAMP(12);
     __builtin_amdgcn_wave_barrier();
-    MPCX_PAIR_NS::stage_out<MPCX_PAIR_NS::kPairs * NU * T, NU * T>(a.u_out + b0 * NU * T, first * NU * T, nb * NU * T, stg + kOutU, lane);
-    MPCX_PAIR_NS::stage_out<MPCX_PAIR_NS::kPairs * 3 * W, 3 * W>(a.x_out + b0 * 3 * W, first * 3 * W, nb * 3 * W, stg + kOutX, lane);
-    if (lane >= first && lane < nb) a.obj_out[b0 + lane] = ((const volatile MPCX_PAIR_NS::lds_double *)stg)[kOutJ + lane];
+    // the wave's record range again, from LDS (kept in registers over the solve it would cost the
+    // chained kernel registers it does not have)
+    const int first_o = RANGE ? flg[kWave] : 0, nb_o = RANGE ? flg[kWave + 1] : nb;
+    MPCX_PAIR_NS::stage_out<MPCX_PAIR_NS::kPairs * NU * T, NU * T>(a.u_out + b0 * NU * T, first_o * NU * T, nb_o * NU * T, stg + kOutU, lane);
+    MPCX_PAIR_NS::stage_out<MPCX_PAIR_NS::kPairs * 3 * W, 3 * W>(a.x_out + b0 * 3 * W, first_o * 3 * W, nb_o * 3 * W, stg + kOutX, lane);
+    if (lane >= first_o && lane < nb_o) a.obj_out[b0 + lane] = ((const volatile MPCX_PAIR_NS::lds_double *)stg)[kOutJ + lane];
     if (live && !s.odd) {
         a.status_out[b] = status;
         if (a.iters_out) a.iters_out[b] = iters;

@@ -1,6 +1,6 @@
 """Independent kernels for the same problem agree with each other: the lane-pair kernel and the
 one-lane-per-instance dense kernel at T = 5, the wavefront-per-instance kernel and the stage-wise
-kernel at T = 12 and 20, all three kernels that take T = 10.  The routing hooks (and the
+kernel at T = 12 and 20, all four kernels that take T = 10.  The routing hooks (and the
 one-lane-per-instance kernel) exist only in the test build of the library, libmpcx_hooks.so,
 which reads them when it loads: each alternative runs in a child process that loads that build."""
 import os
@@ -44,9 +44,11 @@ def _run(env_extra, name, B, T, path):
     ("sim_crab", 5, 1000, ({}, {"MPCX_SINGLE_LANE": "1"})),
     ("dsr_ackermann", 12, 300, ({"MPCX_STAGEWISE": "0"}, {"MPCX_STAGEWISE": "1"})),
     ("diff_drive", 20, 300, ({"MPCX_STAGEWISE": "0"}, {"MPCX_STAGEWISE": "1"})),
-    # mpc.py's controller on all three kernels that take T = 10 (a batch of 4,000 goes to the lane pairs by itself)
+    # mpc.py's controller on all four kernels that take T = 10 (by itself it goes four lanes per instance)
     ("mpc_py", 10, 4000, ({}, {"MPCX_STAGEWISE": "1"})),
-    ("mpc_py", 10, 4000, ({"MPCX_STAGEWISE": "0"}, {"MPCX_STAGEWISE": "1"})),
+    ("mpc_py", 10, 4000, ({}, {"MPCX_T10": "pair"})),
+    ("mpc_py", 10, 1000, ({}, {"MPCX_STAGEWISE": "0"})),
+    ("mpc_py", 10, 37, ({}, {"MPCX_STAGEWISE": "1"})),
 ])
 def test_alternative_kernels_agree(tmp_path, name, T, B, hooks):
     a = _run(hooks[0], name, B, T, str(tmp_path / "a.npz"))
