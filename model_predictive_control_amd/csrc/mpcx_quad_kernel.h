@@ -8,9 +8,13 @@ namespace mpcx {
 #ifndef MPCX_QUAD_K
 #define MPCX_QUAD_K 6
 #endif
+
 constexpr int kQuadIpmIters = MPCX_QUAD_K;   // interior-point iterations before the active-set rounds
 constexpr int kQuadRounds0 = 6, kQuadRounds1 = 4;
 
+// (Instantiated at TT = 5 with two wavefronts per SIMD the same code takes 107 us for the 65,536
+// instances the lane-pair kernel solves in 80 us, 145 us with one: the second wavefront hides
+// latency, but four lanes per instance cost more instructions per instance than two.)
 template <int MODEL, int TT>
 __global__ __launch_bounds__(kWave, MPCX_QUAD_OCC) void k_solve_quad(SolveArgs a)
 {
@@ -25,10 +29,10 @@ __global__ __launch_bounds__(kWave, MPCX_QUAD_OCC) void k_solve_quad(SolveArgs a
     constexpr int SX = quad::padded(3 * W), SU = quad::padded(NU * T), S0 = quad::padded(3);
     constexpr int kInU = kInst * S0, kInXbar = kInU + kInst * SU, kDynOff = kInXbar + kInst * SX;
     constexpr int kOmOff = kDynOff + quad::kDynPerStage * T * kInst;
-    static_assert(kOmOff + T * kInst <= S::kLdsH, "staging, dynamics and yaw rates must fit in the H area");
+    constexpr int kHsDoubles = kOmOff + T * kInst > S::kLdsH ? kOmOff + T * kInst : S::kLdsH;   // T = 10: the H area holds all of it
     constexpr int kOutU = 0, kOutX = kOutU + kInst * SU, kOutJ = kOutX + kInst * SX;
     static_assert(kOutJ + kInst <= kDynOff, "output staging must fit in front of the dynamics");
-    __shared__ double Hs[S::kLdsH];
+    __shared__ double Hs[kHsDoubles];
     __shared__ double Xs[kInst * SX];
     __shared__ int Fs[kWave];
     const mpcx_variant &v = a.v;
