@@ -328,6 +328,9 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--workload", choices=("headline", "mixed4m"), default=None)
     ap.add_argument("--total", type=int, default=MIXED_TOTAL, help="instances of the mixed workload (all ranks together)")
+    ap.add_argument("--gather", choices=("host", "device"), default="host",
+                    help="mixed4m: where the results are gathered: each GPU into pinned host memory (default), or "
+                         "every GPU's controls and statuses onto every GPU by an all-gather over RCCL")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
@@ -437,6 +440,21 @@ def main():
         torch.cuda.synchronize()
         gather_ms = sharding.max_over_ranks((time.perf_counter() - tg) * 1e3, dist, red_dev)
         gathered_bytes = sharding.sum_over_ranks(sum(t.numel() * t.element_size() for h in host for t in h.values()), dist, red_dev)
+        device_gather = None
+        if args.gather == "device" and dist is not None and backend == "nccl":
+            # device-resident alternative: controls and statuses of every rank on every GPU (what a fleet
+            # controller that stays on the GPUs needs), one all-gather per array over xGMI
+            u_mine = torch.cat([p["out"]["u"][:, :2].reshape(p["n"], -1) for p in parts], dim=0)     # first two rows: every variant has them
+            st_mine = torch.cat([p["out"]["status"] for p in parts], dim=0)
+            counts = [hi - lo for lo, hi in sharding.partition(args.total, world)]
+            barrier()
+            td = time.perf_counter()
+            u_all = sharding.all_gather_rows(u_mine, counts, dist)
+            st_all = sharding.all_gather_rows(st_mine, counts, dist)
+            torch.cuda.synchronize()
+            dms = sharding.max_over_ranks((time.perf_counter() - td) * 1e3, dist, red_dev)
+            device_gather = {"ms": dms, "bytes_per_gpu": int(u_all.numel() * 8 + st_all.numel() * 4),
+                             "how": "all-gather of the first two control rows and the statuses onto every GPU (RCCL)"}
 
     if rank == 0:
         achieved = bytes_here / kernel_s / 1e9
@@ -499,6 +517,8 @@ def main():
                                           "by variant so every wavefront is homogeneous, contiguous ranges per GPU; "
                                           "warm-started from their own cold optimum", "total": units_all,
                               "parallelism": f"variant-sorted batch split x{world}, no collective"}
+            if device_gather is not None:
+                line["gather_device"] = device_gather
             line["gather"] = {"ms": gather_ms, "bytes": gathered_bytes,
                               "how": "per-GPU copy of u, x, obj, status, iters into pinned host memory, all ranks at "
                                      "once, slowest rank's time; not part of value"}

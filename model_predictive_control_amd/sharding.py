@@ -78,6 +78,27 @@ def gather_rows(local: np.ndarray, total: int, dist=None) -> np.ndarray | None:
     return out
 
 
+def all_gather_rows(local, counts: Sequence[int], dist=None):
+    """Device-resident alternative to the copy into host memory: every rank ends up with the rows
+    of all ranks, in rank order, in its own memory (one all-gather per array over RCCL / xGMI under
+    the nccl backend; gloo on CPU tensors).  counts[r] = rows of rank r; shards are padded to the
+    largest so that every rank contributes the same shape.  local: a torch tensor [counts[rank], ...]."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if len(counts) != world or local.shape[0] != counts[rank]:
+        raise ValueError("counts must list every rank's rows")
+    most = max(counts)
+    mine = local
+    if local.shape[0] < most:
+        pad = torch.zeros((most - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        mine = torch.cat([local, pad], dim=0)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine.contiguous())
+    return torch.cat([p[:n] for p, n in zip(parts, counts)], dim=0)
+
+
 def variant_segments(counts: Sequence[int], rank: int, world: int) -> List[Tuple[int, int, int]]:
     """A batch of several variants laid out variant after variant (so that every wavefront is
     homogeneous), counts[k] instances of variant k, is split into `world` contiguous ranges; this

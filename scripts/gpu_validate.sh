@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round validation on the GPU box: GPU tests, smoke, bench, kernel-trace stats, and the counter
-# passes (each in a run of its own) of the headline kernel, the T = 10 lane-pair kernel (32,768
-# instances, the largest batch routed to it) and the stage-wise kernel (T = 10 and T = 30 at 65,536).
+# passes (each in a run of its own) of the headline kernel, its chained instantiation, the T = 10
+# four-lane kernel (32,768 and 65,536 instances), the wavefront-per-instance kernel (T = 30, 1,280)
+# and the stage-wise kernel (T = 30 at 65,536, both variants).
 # Every GPU step has its own time limit and the chain stops at the first failure.
 # Afterwards, here: python scripts/summarise_profiles.py <tag>  (writes profiles/).
 set -o pipefail
@@ -36,12 +37,12 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 30
  && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wv_trace -o p -- python3 scripts/prof_solve.py dsr_ackermann 1280 20 30 > $OUT/wv_trace.log 2>&1 \
  && pmc wv_sq_a $SQ_A -- scripts/prof_solve.py dsr_ackermann 1280 5 30 \
  && pmc wv_sq_b $SQ_B -- scripts/prof_solve.py dsr_ackermann 1280 5 30 \
- && pmc p10_fetch FETCH_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \
- && pmc p10_write WRITE_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \
- && pmc p10_sq $SQ_A -- scripts/prof_solve.py mpc_py 32768 3 \
- && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s10_trace -o p -- python3 scripts/prof_solve.py mpc_py 65536 5 > $OUT/s10_trace.log 2>&1 \
- && pmc s10_fetch FETCH_SIZE -- scripts/prof_solve.py mpc_py 65536 5 \
- && pmc s10_write WRITE_SIZE -- scripts/prof_solve.py mpc_py 65536 5 \
+ && pmc q10_fetch FETCH_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \
+ && pmc q10_write WRITE_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \
+ && pmc q10_sq_a $SQ_A -- scripts/prof_solve.py mpc_py 32768 5 \
+ && pmc q10_sq_b $SQ_B -- scripts/prof_solve.py mpc_py 32768 5 \
+ && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q10_trace -o p -- python3 scripts/prof_solve.py mpc_py 65536 200 > $OUT/q10_trace.log 2>&1 \
+ && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/q10b_trace -o p -- python3 scripts/prof_solve.py mpc_py 32768 200 > $OUT/q10b_trace.log 2>&1 \
  && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/st_trace -o p -- python3 scripts/prof_solve.py dsr_ackermann 65536 5 30 > $OUT/st_trace.log 2>&1 \
  && pmc st_fetch FETCH_SIZE -- scripts/prof_solve.py dsr_ackermann 65536 5 30 \
  && pmc st_write WRITE_SIZE -- scripts/prof_solve.py dsr_ackermann 65536 5 30 \

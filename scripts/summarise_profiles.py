@@ -128,24 +128,21 @@ if pw:
            "valu_busy_frac": (pw.get("SQ_ACTIVE_INST_VALU", 0.0) / pw["SQ_WAVE_CYCLES"]) if pw.get("SQ_WAVE_CYCLES") else None, "how": how}
     json.dump(rec, open(os.path.join(PROF, f"{rnd}_wave_T30_counters.json"), "w"), indent=1)
     print("wave kernel T30", ns, "ns")
-# T = 10 kernel
-t = traffic("p10_fetch", "p10_write", "k_solve_pair10")
-pw = sq(["p10_sq"], "k_solve_pair10")
+# T = 10: four lanes per instance (mpc.py's controller)
+st = kernel_stats("q10_trace", "p", f"{rnd}_quad_T10_65536_kernel_stats.csv")
+st32 = kernel_stats("q10b_trace", "p", f"{rnd}_quad_T10_32768_kernel_stats.csv")
+t = traffic("q10_fetch", "q10_write", "k_solve_quad")
+pw = sq(["q10_sq_a", "q10_sq_b"], "k_solve_quad")
 if t or pw:
-    rec = {"kernel": "k_solve_pair10<dual-steer>", "variant": "mpc_py", "T": 10, "batch": 32768, "csrc_sha": sha,
-           "algorithmic_bytes": 32768 * 1209, "traffic": t, "per_wave": pw, "how": how}
-    json.dump(rec, open(os.path.join(PROF, f"{rnd}_pair10_counters.json"), "w"), indent=1)
-    print("pair10 traffic", t and t["bytes_per_launch"], "algorithmic", 32768 * 1209)
-# stage-wise kernel, T = 10 (mpc.py's controller at the benchmark's batch)
-st = kernel_stats("s10_trace", "p", f"{rnd}_stage_T10_kernel_stats.csv")
-t = traffic("s10_fetch", "s10_write", "k_solve_stage")
-if t:
-    ns, calls = avg_ns(st, "k_solve_stage")
-    rec = {"kernel": "k_solve_stage<dual steer>", "variant": "mpc_py", "T": 10, "batch": 65536, "csrc_sha": sha,
-           "avg_ns": ns, "launches": calls, "hbm_read_bytes": t["fetch_bytes"], "hbm_write_bytes": t["write_bytes"],
-           "hbm_GBps": (t["bytes_per_launch"]) / ns if ns else None, "algorithmic_bytes": 65536 * 1209, "how": how}
-    json.dump(rec, open(os.path.join(PROF, f"{rnd}_stage_T10_traffic.json"), "w"), indent=1)
-    print("stage T10", rec["avg_ns"], "ns", t["bytes_per_launch"] / 1e9, "GB per launch")
+    ns, calls = avg_ns(st, "k_solve_quad")
+    ns32, calls32 = avg_ns(st32, "k_solve_quad")
+    rec = {"kernel": "k_solve_quad<dual-steer, T=10>", "variant": "mpc_py", "T": 10, "batch": 32768, "csrc_sha": sha,
+           "algorithmic_bytes": 32768 * 1209, "traffic": t, "per_wave": pw,
+           "valu_busy_frac": (pw.get("SQ_ACTIVE_INST_VALU", 0.0) / pw["SQ_WAVE_CYCLES"]) if pw and pw.get("SQ_WAVE_CYCLES") else None,
+           "avg_ns_32768": ns32, "launches_32768": calls32, "avg_ns_65536": ns, "launches_65536": calls,
+           "note": "kernel-trace averages over 200 back-to-back warm launches (settled clock)", "how": how}
+    json.dump(rec, open(os.path.join(PROF, f"{rnd}_quad10_counters.json"), "w"), indent=1)
+    print("quad10 traffic", t and t["bytes_per_launch"], "algorithmic", 32768 * 1209, "avg ns 32768/65536", ns32, ns)
 # stage-wise kernel, T = 30
 st = kernel_stats("st_trace", "p", f"{rnd}_stage_T30_kernel_stats.csv")
 kernel_stats("sd_trace", "p", f"{rnd}_stage_T30_dsr_diff_kernel_stats.csv")

@@ -55,6 +55,14 @@ def _worker(rank, world, port, total, outdir):
         assert mine["x0"].shape[0] == hi - lo
         res = orc.iterative_batch(ov, mine["x0"], mine["xref"], None, None, nthreads=1)
         u_all = sharding.gather_rows(res["u"], total, dist)
+        # the device-resident flavour of the gather (here on CPU tensors over gloo): every rank gets all rows
+        import torch
+        counts = [b - a for a, b in sharding.partition(total, world)]
+        everywhere = sharding.all_gather_rows(torch.from_numpy(res["u"]), counts, dist)
+        assert everywhere.shape[0] == total
+        lo_, hi_ = sharding.partition(total, world)[rank]
+        assert np.array_equal(everywhere[lo_:hi_].numpy(), res["u"])
+        np.save(os.path.join(outdir, f"allgather_{rank}.npy"), everywhere.numpy())
         # the slowest rank sets the clock; every rank sees the same number
         slow = sharding.max_over_ranks(1.0 + rank, dist)
         assert slow == float(world)
