@@ -424,6 +424,7 @@ class SegmentedLoop:
         self._ind_tmp = torch.zeros(B, dtype=torch.int32, device=dev)
         self._mode_ids = torch.arange(M + 1, dtype=torch.int64, device=dev)
         self._rest = torch.full((B,), M, dtype=torch.int64, device=dev)
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(M)]
         self.device_resident = self._range_solve_available()
         self._enter_segment(torch.nonzero(self.finished == 0).flatten())
         if self.log is not None:
@@ -496,10 +497,18 @@ class SegmentedLoop:
         g_x0, g_xref = self.x0.index_select(0, order), self.xref.index_select(0, order)
         g_up, g_hp = self.uprev.index_select(0, order), self.has_prev.index_select(0, order)
         so = self._sorted
+        # one launch per mode, each on a stream of its own: a mode's run fills only part of the chip,
+        # and the runs touch disjoint rows, so the launches may overlap; the main stream waits for all
+        main = torch.cuda.current_stream()
         for m, v in enumerate(self.variants):
-            _lib.check(lib.mpcx_solve_range_batch(C.byref(v), self.B, C.c_void_p(bounds.data_ptr() + 4 * m), _ptr(g_x0),
-                                                  _ptr(g_xref), _ptr(g_up), _ptr(g_hp), _ptr(so["u"]), _ptr(so["x"]),
-                                                  _ptr(so["obj"]), _ptr(so["status"]), _ptr(so["iters"]), st))
+            side = self._streams[m]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _lib.check(lib.mpcx_solve_range_batch(C.byref(v), self.B, C.c_void_p(bounds.data_ptr() + 4 * m), _ptr(g_x0),
+                                                      _ptr(g_xref), _ptr(g_up), _ptr(g_hp), _ptr(so["u"]), _ptr(so["x"]),
+                                                      _ptr(so["obj"]), _ptr(so["status"]), _ptr(so["iters"]), _stream()))
+        for side in self._streams:
+            main.wait_stream(side)
         o = self.out
         # rows past the last run (vehicles at rest) carry stale values; the advance ignores them (done != 0)
         o["u"].index_copy_(0, order, so["u"])

@@ -23,7 +23,7 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 30
  && tail -1 $OUT/smoke.log \
  && timeout -k 10 300 python bench.py --steps 50 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err \
  && timeout -k 10 300 python bench.py --workload mixed4m > $OUT/mixed4m.json 2> $OUT/mixed4m.err \
- && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1 \
+ && timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/trace.log 2>&1 \
  && pmc pmc_fetch FETCH_SIZE -- bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs \
  && pmc pmc_write WRITE_SIZE -- bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-other-configs \
  && pmc sq5_a $SQ_A -- scripts/prof_solve.py dsr_ackermann 65536 5 \
