@@ -1284,15 +1284,19 @@ static int64_t stage_chunk(int64_t B)
     return B < cap ? ((B + kWave - 1) / kWave) * kWave : cap;
 }
 
-// Largest batch the wavefront-per-instance kernel takes: what the chip holds at once (256 CUs,
-// per CU as many wavefronts as LDS and registers allow).  One such round takes less than the
-// latency of a single stage-wise wavefront (T = 30: 0.93 ms against 1.58 ms; T = 12: 0.25-0.38 ms
-// against 0.64 ms); a second round does not.
+// Largest batch the wavefront-per-instance kernel takes: what the chip holds at once (256 CUs, per
+// CU as many wavefronts as LDS and registers allow, in whole wavefronts per SIMD: a fifth wavefront
+// on a CU shares a SIMD with another and doubles the launch's time).  One such round takes less than
+// the latency of a single stage-wise wavefront (measured, warm: T = 30, 1,024 instances and fewer:
+// 0.88 ms against 1.29 ms, while 1,280 take 1.80 ms against 1.43 ms; T = 12, 3,072: 0.38 ms against
+// 0.54 ms); a second round does not.
 static int64_t wave_batch_max(int T)
 {
     const int64_t by_lds = (160 * 1024) / ((int64_t)wave_lds_doubles(T) * (int64_t)sizeof(double));
     const int64_t by_regs = 12;   // 3 wavefronts per SIMD at the kernel's register count
-    return 256 * (by_lds < by_regs ? by_lds : by_regs);
+    int64_t per_cu = by_lds < by_regs ? by_lds : by_regs;
+    if (per_cu > 4) per_cu = per_cu / 4 * 4;
+    return 256 * per_cu;
 }
 
 enum SolvePath { kPathPair5, kPathReg5, kPathPair10, kPathQuad10, kPathWave, kPathStage };

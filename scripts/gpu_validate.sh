@@ -34,9 +34,9 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 30
  && pmc ch_sq_b $SQ_B -- scripts/prof_solve.py sim_ackermann 65536 5 \
  && pmc ch_fetch FETCH_SIZE -- scripts/prof_solve.py sim_ackermann 65536 5 \
  && pmc ch_write WRITE_SIZE -- scripts/prof_solve.py sim_ackermann 65536 5 \
- && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wv_trace -o p -- python3 scripts/prof_solve.py dsr_ackermann 1280 20 30 > $OUT/wv_trace.log 2>&1 \
- && pmc wv_sq_a $SQ_A -- scripts/prof_solve.py dsr_ackermann 1280 5 30 \
- && pmc wv_sq_b $SQ_B -- scripts/prof_solve.py dsr_ackermann 1280 5 30 \
+ && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wv_trace -o p -- python3 scripts/prof_solve.py dsr_ackermann 1024 20 30 > $OUT/wv_trace.log 2>&1 \
+ && pmc wv_sq_a $SQ_A -- scripts/prof_solve.py dsr_ackermann 1024 5 30 \
+ && pmc wv_sq_b $SQ_B -- scripts/prof_solve.py dsr_ackermann 1024 5 30 \
  && pmc q10_fetch FETCH_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \
  && pmc q10_write WRITE_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \
  && pmc q10_sq_a $SQ_A -- scripts/prof_solve.py mpc_py 32768 5 \

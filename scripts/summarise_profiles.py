@@ -123,7 +123,7 @@ st = kernel_stats("wv_trace", "p", f"{rnd}_wave_T30_kernel_stats.csv")
 pw = sq(["wv_sq_a", "wv_sq_b"], "k_solve_wave")
 if pw:
     ns, calls = avg_ns(st, "k_solve_wave")
-    rec = {"kernel": "k_solve_wave<dual-steer>", "variant": "dsr_ackermann", "T": 30, "batch": 1280, "csrc_sha": sha, "avg_ns": ns,
+    rec = {"kernel": "k_solve_wave<dual-steer>", "variant": "dsr_ackermann", "T": 30, "batch": 1024, "csrc_sha": sha, "avg_ns": ns,
            "launches": calls, "per_wave": pw,
            "valu_busy_frac": (pw.get("SQ_ACTIVE_INST_VALU", 0.0) / pw["SQ_WAVE_CYCLES"]) if pw.get("SQ_WAVE_CYCLES") else None, "how": how}
     json.dump(rec, open(os.path.join(PROF, f"{rnd}_wave_T30_counters.json"), "w"), indent=1)

@@ -66,3 +66,35 @@ def test_random_controller(eng, seed):
     ref2 = orc.iterative_batch(ov, x0, xref, up, hp, nthreads=8)
     out2 = eng.solve_batch(v, x0, xref, up, hp)
     compare(out2, ref2, u_tol=1e-6, x_tol=1e-6, obj_tol=1e-8, problem=dict(ov=ov, x0=x0, xref=xref, uref=up, has_prev=hp))
+
+
+def _horizon_10_case(seed):
+    """A random controller that the four-lanes-per-instance kernel takes: T = 10, unchained, a finite
+    box on both free channels (rate bounds may be absent), odd batch sizes on both sides of the
+    16-instance wavefront and of the 16,384 instances the chip holds at once."""
+    rng = np.random.default_rng(7000 + seed)
+    base = ["diff_drive", "dsr_ackermann", "dsr_crab", "dsr_diff", "mpc_py"][seed % 5]
+    kw = _random_overrides(rng, base)
+    kw["T"] = 10
+    nu = 2 if base == "diff_drive" else 4
+    um = list(kw["umax"])
+    for i in range(0, nu, 2):
+        if not math.isfinite(um[i]):
+            um[i] = float(rng.uniform(0.3, 1.0))
+    kw["umax"] = tuple(um)
+    B = int(rng.choice([1, 15, 16, 17, 250, 1023, 4099, 16385, 20011]))
+    return base, kw, B
+
+
+@pytest.mark.parametrize("seed", range(15))
+def test_random_controller_at_horizon_10(eng, seed):
+    base, kw, B = _horizon_10_case(seed)
+    v, ov, x0, xref = make_problem(base, B, seed=90 + seed, **kw)
+    ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=16)
+    out = eng.solve_batch(v, x0, xref)
+    compare(out, ref, u_tol=1e-6, x_tol=1e-6, obj_tol=1e-8, problem=dict(ov=ov, x0=x0, xref=xref))
+    hp = (np.arange(B) % 3 != 0).astype(np.uint8)
+    up = np.where(np.isnan(ref["u"]), 0.0, ref["u"])
+    ref2 = orc.iterative_batch(ov, x0, xref, up, hp, nthreads=16)
+    out2 = eng.solve_batch(v, x0, xref, up, hp)
+    compare(out2, ref2, u_tol=1e-6, x_tol=1e-6, obj_tol=1e-8, problem=dict(ov=ov, x0=x0, xref=xref, uref=up, has_prev=hp))

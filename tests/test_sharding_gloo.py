@@ -122,3 +122,12 @@ def test_bench_py_decides_to_spawn_before_touching_the_gpu():
     assert bench.ranks_to_spawn(8, {}) == 8
     assert bench.ranks_to_spawn(1, {}) == 0
     assert bench.ranks_to_spawn(8, {"WORLD_SIZE": "8", "RANK": "3"}) == 0     # already under a launcher
+
+
+def test_bench_byte_formulas_match_the_stated_figures():
+    """Algorithmic bytes per solve and per fused tick: 16 NU T + 48 (T+1) + 41, and the same with the
+    reference-window read replaced by state, index, course id and course points."""
+    import bench
+    assert bench.algorithmic_bytes(2, 5) == 489 and bench.algorithmic_bytes(4, 5) == 649
+    assert bench.algorithmic_bytes(4, 10) == 1209 and bench.algorithmic_bytes(4, 30) == 3449
+    assert bench.fused_tick_bytes(2, 5) == 565 and bench.fused_tick_bytes(4, 5) == 725
