@@ -88,10 +88,12 @@ int mpcx_variant_by_name(const char *name, mpcx_variant *out);
 
 /* Bytes of device workspace mpcx_solve_batch / mpcx_linear_mpc_batch need for B
  * instances of this variant: 0 for the kernels that live in registers and LDS (T = 5 and
- * T = 10 at every batch size, and batches up to T = 32 that the chip holds at once),
- * otherwise the per-lane
- * arrays of the stage-wise kernel for one launch (440 T bytes per instance, at most
- * 262,144 instances per launch).  The library keeps one grow-only buffer per device for
+ * T = 10 at every batch size), otherwise the per-lane arrays of the stage-wise kernel for one
+ * launch (440 T bytes per instance, at most 262,144 instances per launch).  Small batches at other
+ * horizons up to T = 32 are solved by a kernel that needs none, but are followed by a stage-wise
+ * pass that solves again whatever that kernel reports as MPCX_ST_INACCURATE (rare; the pass
+ * returns at once otherwise, and is left out when uprev and u_out are the same buffer, since it
+ * starts from the same inputs), so they count as needing the workspace too.  The library keeps one grow-only buffer per device for
  * it; calls that need it are serialised per device (each waits on the device for the
  * previous one, whatever its stream), the first one allocates, and none of them may be
  * part of a stream capture.  The answer is for mpcx_solve_batch; for mpcx_linear_mpc_batch,

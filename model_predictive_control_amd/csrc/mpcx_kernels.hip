@@ -265,11 +265,12 @@ namespace mpcx {
 // ------------------------------------------------------------------------------------
 // solve: one wavefront per instance (horizons beyond the lane-pair kernels, n = 2T <= 64)
 // ------------------------------------------------------------------------------------
-#ifndef MPCX_WAVE_K
-#define MPCX_WAVE_K 6
-#endif
-constexpr int kWaveIpmIters = MPCX_WAVE_K;   // interior-point iterations before the active-set rounds
-constexpr int kWaveRounds0 = 8, kWaveRounds1 = 5;
+constexpr int kWaveAttempts = 3;
+constexpr int kWaveIpmCap = 40;      // interior-point iterations at most per attempt but the last
+// complementarity at which an attempt hands over to the active-set rounds (0: converged), and
+// the rounds it may take
+__device__ const double kWaveSwitchMu[kWaveAttempts] = {kSwitchMu, 1e-9, 0.0};
+__device__ const int kWaveRounds[kWaveAttempts] = {5, 5, 5};
 
 __host__ __device__ inline int wave_lds_doubles(int T)
 {
@@ -451,17 +452,23 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
     // solve
     c.w = 0.0; c.lamU = c.lamL = c.nuU = c.nuL = 0.0;
     if (!skip) {
-        int st = MPCX_ST_OK, it = 0;
-        wave::ipm(c, a.max_iter < kWaveIpmIters ? a.max_iter : kWaveIpmIters, true, st, it);
-        iters += it;
-        MPCX_STAMP(3);
-        bool settled = wave::pdas(c, kWaveRounds0, hmax);
-        MPCX_STAMP(4);
-        if (!settled) {
-            wave::ipm(c, a.max_iter, false, st, it);
+        // Attempts: the interior point down to a complementarity at which the active set can
+        // usually be read off the iterate, then the active-set rounds; if the rounds do not settle
+        // the interior point goes on from where it stood (nothing is redone) and they are tried
+        // again, the last time from a converged iterate, whose own verdict stands if they still fail.
+        wave::Iterate keep;
+        bool settled = false;
+        for (int attempt = 0; attempt < kWaveAttempts && !settled; ++attempt) {
+            int st = MPCX_ST_OK, it = 0;
+            if (attempt > 0) keep.restore(c);
+            const int cap = a.max_iter < kWaveIpmCap || attempt + 1 == kWaveAttempts ? a.max_iter : kWaveIpmCap;
+            wave::ipm(c, cap, kWaveSwitchMu[attempt], attempt > 0, st, it);
             iters += it;
             status = st;
-            settled = wave::pdas(c, kWaveRounds1, hmax);
+            keep.save(c);
+            if (attempt == 0) { MPCX_STAMP(3); }
+            settled = wave::pdas(c, kWaveRounds[attempt], hmax);
+            if (attempt == 0) { MPCX_STAMP(4); }
         }
         if (settled) status = MPCX_ST_OK;
     }
@@ -540,7 +547,10 @@ __device__ const int kStageRounds[kStageAttempts] = {MPCX_STAGE_R0, 6, 6};
 #ifndef MPCX_STAGE_OCC
 #define MPCX_STAGE_OCC 1   // wavefronts per SIMD the register budget is set for
 #endif
-template <int MODEL>
+// REDO: a second pass over a batch that another solve kernel has already answered: only the
+// instances that kernel left MPCX_ST_INACCURATE are solved again (from the same inputs) and
+// rewritten; a wavefront without one returns at once.
+template <int MODEL, bool REDO = false>
 __global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs a, double *ws)
 {
     constexpr int NU = MODEL == MPCX_MODEL_DIFF_DRIVE ? 2 : 4;
@@ -549,8 +559,12 @@ __global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs
     const int64_t slot = (int64_t)blockIdx.x * kWave + threadIdx.x;
     s.bind(ws, v.T, blockIdx.x, threadIdx.x);
     int64_t b = slot;
-    const bool live = b < a.B;
+    bool live = b < a.B;
     if (!live) b = a.B - 1;
+    if (REDO) {
+        live = live && a.status_out[b] == MPCX_ST_INACCURATE;
+        if (!__any(live)) return;
+    }
     const int T = v.T, W = T + 1;
 
     stagewise::Problem p;
@@ -1327,7 +1341,7 @@ static SolvePath choose_path(const mpcx_variant *v, int64_t B, bool chained)
 
 // The stage-wise kernel over a batch, `chunk` instances (a multiple of 64) per launch, every
 // launch using the same workspace `ws` (launches on one stream run one after the other).
-static int launch_stage_chunks(const SolveArgs &a, hipStream_t st, double *ws, int64_t chunk)
+static int launch_stage_chunks(const SolveArgs &a, hipStream_t st, double *ws, int64_t chunk, bool redo = false)
 {
     const mpcx_variant *v = &a.v;
     const int NU = v->nu, T = v->T, W = T + 1;
@@ -1347,8 +1361,13 @@ static int launch_stage_chunks(const SolveArgs &a, hipStream_t st, double *ws, i
         c.status_out = a.status_out + off;
         if (a.iters_out) c.iters_out = a.iters_out + off;
         const dim3 grid((unsigned)((c.B + kWave - 1) / kWave));
-        if (m == 0) hipLaunchKernelGGL((k_solve_stage<0>), grid, block, 0, st, c, ws);
-        else hipLaunchKernelGGL((k_solve_stage<1>), grid, block, 0, st, c, ws);
+        if (redo) {
+            if (m == 0) hipLaunchKernelGGL((k_solve_stage<0, true>), grid, block, 0, st, c, ws);
+            else hipLaunchKernelGGL((k_solve_stage<1, true>), grid, block, 0, st, c, ws);
+        } else {
+            if (m == 0) hipLaunchKernelGGL((k_solve_stage<0>), grid, block, 0, st, c, ws);
+            else hipLaunchKernelGGL((k_solve_stage<1>), grid, block, 0, st, c, ws);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_solve_stage launch");
     }
@@ -1386,6 +1405,7 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
     const dim3 block(kWave);
     clear_stale_error();
     const int m = v->model == MPCX_MODEL_DIFF_DRIVE ? 0 : 1;
+    bool redo = false;
     if (a.range && choose_path(v, a.B, chained) != kPathPair5)
         return fail(MPCX_E_UNSUPPORTED, "a device-resident instance range is taken by the T = 5 lane-pair kernel only");
     switch (choose_path(v, a.B, chained)) {
@@ -1455,7 +1475,15 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
         else hipLaunchKernelGGL((k_solve_wave<1>), wgrid, block, lds, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_solve_wave launch");
-        return 0;
+        // About one instance in 10^5 to 10^6 of hard random controllers is left INACCURATE by this
+        // kernel (its interior-point iterate short of tolerance and its active-set rounds not
+        // settled) where the stage-wise kernel reaches the optimum: a second, stage-wise pass
+        // solves those again from the same inputs, which it can only do while the incoming
+        // controls have not been overwritten by the answer.  A wavefront of that pass that finds
+        // nothing to do returns at once.  Forcing this kernel through the test hook shows it raw.
+        if (g_stagewise == 0 || (a.uin && (const void *)a.uin == (const void *)a.u_out)) return 0;
+        redo = true;
+        break;
     }
     case kPathStage:
         break;
@@ -1476,7 +1504,7 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
                         (long long)(kScratchBytes / ((size_t)stage_doubles_per_instance(v->T) * sizeof(double)) / kWave * kWave));
         double *ws = nullptr;
         if (int rc = scratch_of_device(dev, &ws)) return rc;
-        return launch_stage_chunks(a, st, ws, slots);
+        return launch_stage_chunks(a, st, ws, slots, redo);
     }
     // launches chunked so that the grow-only buffer stays bounded
     const int64_t chunk = stage_chunk(a.B);
@@ -1502,7 +1530,7 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
         e = hipStreamWaitEvent(st, g_ws_event[dev], 0);
         if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
     }
-    if (int rc = launch_stage_chunks(a, st, g_ws[dev], chunk)) return rc;
+    if (int rc = launch_stage_chunks(a, st, g_ws[dev], chunk, redo)) return rc;
     e = hipEventRecord(g_ws_event[dev], st);
     if (e != hipSuccess) return hip_fail(e, "hipEventRecord");
     g_ws_event_set[dev] = true;
@@ -1581,7 +1609,9 @@ int mpcx_variant_by_name(const char *name, mpcx_variant *out)
 int64_t mpcx_workspace_bytes(const mpcx_variant *v, int64_t B)
 {
     if (check_variant(v) != 0 || B < 0) return MPCX_E_ARG;
-    if (choose_path(v, B, v->chain > 1) != kPathStage) return 0;   // registers / LDS only
+    const SolvePath path = choose_path(v, B, v->chain > 1);
+    // the wavefront-per-instance kernel is followed by a stage-wise pass over what it left unsettled
+    if (path != kPathStage && !(path == kPathWave && g_stagewise != 0)) return 0;   // registers / LDS only
     return stage_doubles_per_instance(v->T) * stage_chunk(B) * (int64_t)sizeof(double);
 }
 

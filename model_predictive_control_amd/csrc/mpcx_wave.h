@@ -9,10 +9,12 @@
 // them fit in under 30 KB at n = 60 and five instances share a compute unit: the kernel issues
 // one instruction stream per instance, and what it needs most is enough of them per SIMD.
 //
-// Solver = the same scheme as the lane-pair kernel: a fixed number of interior-point
-// iterations (predictor-corrector, centring from the predictor's step lengths) to find the
-// active set, then primal-dual active-set rounds that certify the KKT conditions of the QP;
-// whatever does not settle takes a converged interior-point solve and the rounds again.
+// Solver = the scheme of the stage-wise kernel on the condensed problem: interior-point
+// iterations (predictor-corrector, centring from the predictor's step lengths) until the
+// complementarity is small enough to read the active set off the iterate, then primal-dual
+// active-set rounds that certify the KKT conditions of the QP; if they do not settle the
+// interior point goes on from where it stood and the rounds are tried again.  One instance per
+// wavefront: an instance takes the iterations it needs and waits for no other.
 #pragma once
 #include "mpcx_device.h"
 
@@ -256,25 +258,43 @@ __device__ __forceinline__ void add_terms(const Ctx &c, double db, double dr)
 // C' applied to per-constraint values: box part `tb` (upper minus lower) and rate part `tr`.
 __device__ __forceinline__ double ct_apply(const Ctx &c, double tb, double tr) { return tb + from_prev(tr, c.lane) - tr; }
 
-// Predictor-corrector interior point (see pair kernels for the formulas).  `fixed`: exactly
-// max_iter iterations.  Status / iteration count are wave-uniform: one instance per wave.
-__device__ __forceinline__ void ipm(Ctx &c, int max_iter, bool fixed, int &status, int &iters)
+// The interior point's iterate, kept across the active-set rounds (which overwrite it) so that
+// a later attempt can go on from it.
+struct Iterate {
+    double w, lamU, lamL, nuU, nuL;
+    __device__ __forceinline__ void save(const Ctx &c) { w = c.w; lamU = c.lamU; lamL = c.lamL; nuU = c.nuU; nuL = c.nuL; }
+    __device__ __forceinline__ void restore(Ctx &c) const { c.w = w; c.lamU = lamU; c.lamL = lamL; c.nuU = nuU; c.nuL = nuL; }
+};
+
+// Predictor-corrector interior point (see pair kernels for the formulas).  With mu_stop > 0 it
+// stops once the complementarity is below mu_stop and the dual residual small (the active set
+// can then be read off the iterate); otherwise it runs to convergence; max_iter iterations at
+// most either way.  `resume` goes on from the iterate in `c`
+// instead of starting over.  Status / iteration count are wave-uniform: one instance per wave.
+__device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool resume, int &status, int &iters)
 {
     const int i = c.lane;
-    {
+    if (!resume) {
         // strictly feasible start: every stage at the middle of its channel's first-stage window
         double wc = c.hb ? 0.5 * (c.lo + c.hi) : 0.0;     // valid on lanes 0, 1
         wc = __shfl(wc, i & 1, kWave);
         c.w = c.act ? wc : 0.0;
-        c.lamU = c.hb ? kMu0 * rcp_nr(dmax(c.hi - wc, kSlackMin)) : 0.0;
-        c.lamL = c.hb ? kMu0 * rcp_nr(dmax(wc - c.lo, kSlackMin)) : 0.0;
-        const double l0 = c.hr ? kMu0 * rcp_nr(c.rr) : 0.0;
+        // The complementarity a constraint starts at follows the gradient (at zero controls) of
+        // its own control, capped by the instance's largest: with stage weights that grow like 2^t
+        // (mpc_dsr.py:349) the gradient reaches 1e7, and from 0.1 everywhere the iteration spends
+        // 25 steps raising the late stages' multipliers to that scale.
+        const double gi = c.act ? fabs(c.g) : 0.0;
+        const double mu0 = kMu0 * dmax(1.0, wmax(gi));
+        const double mub = dmin(mu0, kMu0 * dmax(1.0, gi));
+        const double mur = dmin(mu0, kMu0 * dmax(1.0, dmax(gi, from_next(gi, i))));
+        c.lamU = c.hb ? mub * rcp_nr(dmax(c.hi - wc, kSlackMin)) : 0.0;
+        c.lamL = c.hb ? mub * rcp_nr(dmax(wc - c.lo, kSlackMin)) : 0.0;
+        const double l0 = c.hr ? mur * rcp_nr(c.rr) : 0.0;
         c.nuU = l0; c.nuL = l0;
     }
     status = MPCX_ST_FAILED;
     iters = 0;
     for (int it = 0;; ++it) {
-        if (fixed && it >= max_iter) { iters = it; return; }
         const double hw = matvec<true>(c, c.w);
         // slacks, barrier terms
         const double wn = from_next(c.w, i);
@@ -293,8 +313,9 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, bool fixed, int &statu
         const double scale = dmax(1.0, wmax(c.act ? dmax(fabs(hw - c.g), dmax(fabs(c.g), fabs(ctl))) : 0.0)) + 1.0;
         const bool conv = rdmax <= kTolD * scale && mu <= kTolMu;
         if (conv) { status = MPCX_ST_OK; iters = it; return; }
+        const bool handover = mu_stop > 0.0 && mu <= mu_stop && rdmax <= kSwitchD * scale;
         // no constraint at all: zero complementarity by definition, the iteration is a Newton step
-        if ((c.inv_m > 0.0 && mu < kMuFloor) || it >= max_iter || !finite_d(mu + rdmax)) {
+        if (handover || (c.inv_m > 0.0 && mu < kMuFloor) || it >= max_iter || !finite_d(mu + rdmax)) {
             iters = it;
             status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
             return;
@@ -347,7 +368,7 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
 {
     const int i = c.lane;
     const double wbak = c.w;
-    const double rho = dmin(1e5 * hmax, kRhoCap);
+    double rho = dmin(1e5 * hmax, kRhoCap);
     bool au, al, bu, bl;
     {
         const double dv = from_next(c.w, i) - c.w;
@@ -356,7 +377,7 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
         c.lamU = au ? c.lamU : 0.0; c.lamL = al ? c.lamL : 0.0;
         c.nuU = bu ? c.nuU : 0.0; c.nuL = bl ? c.nuL : 0.0;
     }
-    bool changed = true, accepted = false;
+    bool changed = true, accepted = false, eased = false;
     for (int round = 0;; ++round) {
         const double hw = matvec<true>(c, c.w);
         const double dv = from_next(c.w, i) - c.w;
@@ -373,9 +394,20 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
         const double scale = dmax(1.0, wmax(c.act ? dmax(fabs(c.g), fabs(hw - c.g)) : 0.0)) + 1.0;
         viol = wmax(viol); cact = wmax(cact); neg = wmax(neg);
         const bool fin = finite_d(wsum(c.act ? gl + ga + c.w : 0.0));   // max() drops NaN operands
-        if (!changed && fin && stat <= 1e-10 * scale && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) {
+        const bool on_set = !changed && fin && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale;
+        if (on_set && stat <= 1e-10 * scale) {
             accepted = true;
             break;
+        }
+        // On its active set with the set at rest, yet not stationary: the multiplier update
+        // lam += rho c(w) carries the rounding of the controls (an ulp of w, 1e-16) times rho into
+        // the multipliers, which for a large Hessian and a small gradient is above the tolerance.
+        // The remaining rounds (and two more) use a hundredth of the penalty: the point is already
+        // on the constraints, so the slower contraction costs little, and the floor drops with it.
+        if (on_set && !eased) {
+            eased = true;
+            rho *= 1e-2;
+            max_rounds += 2;
         }
         if (round >= max_rounds || !fin) break;
         MPCX_STAMP(8);
@@ -396,6 +428,13 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
         const bool bu2 = c.hr && ((bu && nu >= ntol) || ru2 > 1e-12), bl2 = c.hr && ((bl && nl >= ntol) || rl2 > 1e-12);
         const bool ch = au2 != au || al2 != al || bu2 != bu || bl2 != bl;
         changed = __any(ch) != 0;
+#ifdef MPCX_WAVE_TRACE
+        if (blockIdx.x == MPCX_WAVE_TRACE) {
+            if (i == 0) printf("round %d stat %.3e scale %.3e viol %.3e cact %.3e neg %.3e\n", round, stat, scale, viol, cact, neg);
+            if (ch) printf("   lane %d: au %d->%d al %d->%d bu %d->%d bl %d->%d | lu %.3e ll %.3e nu %.3e nl %.3e | vu2 %.3e vl2 %.3e ru2 %.3e rl2 %.3e ntol %.3e\n",
+                           i, au, au2, al, al2, bu, bu2, bl, bl2, lu, ll, nu, nl, vu2, vl2, ru2, rl2, ntol);
+        }
+#endif
         au = au2; al = al2; bu = bu2; bl = bl2;
         c.lamU = au ? dmax(lu, 0.0) : 0.0; c.lamL = al ? dmax(ll, 0.0) : 0.0;
         c.nuU = bu ? dmax(nu, 0.0) : 0.0; c.nuL = bl ? dmax(nl, 0.0) : 0.0;
