@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round validation on the GPU box: GPU tests, smoke, bench, kernel-trace stats, and the counter
 # passes (each in a run of its own) of the headline kernel, its chained instantiation, the T = 10
-# four-lane kernel (32,768 and 65,536 instances), the wavefront-per-instance kernel (T = 30, 1,280)
+# four-lane kernel (32,768 and 65,536 instances), the wavefront-per-instance kernel (T = 30, 1,024, both variants)
 # and the stage-wise kernel (T = 30 at 65,536, both variants).
 # Every GPU step has its own time limit and the chain stops at the first failure.
 # Afterwards, here: python scripts/summarise_profiles.py <tag>  (writes profiles/).
@@ -35,6 +35,7 @@ timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --tb=short --timeout 30
  && pmc ch_fetch FETCH_SIZE -- scripts/prof_solve.py sim_ackermann 65536 5 \
  && pmc ch_write WRITE_SIZE -- scripts/prof_solve.py sim_ackermann 65536 5 \
  && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wv_trace -o p -- python3 scripts/prof_solve.py dsr_ackermann 1024 20 30 > $OUT/wv_trace.log 2>&1 \
+ && timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/wd_trace -o p -- python3 scripts/prof_solve.py dsr_diff 1024 20 30 > $OUT/wd_trace.log 2>&1 \
  && pmc wv_sq_a $SQ_A -- scripts/prof_solve.py dsr_ackermann 1024 5 30 \
  && pmc wv_sq_b $SQ_B -- scripts/prof_solve.py dsr_ackermann 1024 5 30 \
  && pmc q10_fetch FETCH_SIZE -- scripts/prof_solve.py mpc_py 32768 5 \

@@ -120,6 +120,7 @@ if t or pw:
     print("chain kernel", ns, "ns", t and t["bytes_per_launch"])
 # wavefront-per-instance kernel, T = 30, the batch the chip holds at once
 st = kernel_stats("wv_trace", "p", f"{rnd}_wave_T30_kernel_stats.csv")
+kernel_stats("wd_trace", "p", f"{rnd}_wave_T30_dsr_diff_kernel_stats.csv")
 pw = sq(["wv_sq_a", "wv_sq_b"], "k_solve_wave")
 if pw:
     ns, calls = avg_ns(st, "k_solve_wave")
