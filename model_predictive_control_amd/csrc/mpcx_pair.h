@@ -434,8 +434,8 @@ __device__ __forceinline__ void ipm(State &s, int max_iter, bool fixed, bool ski
 // H + rho A'A), a first-order multiplier update, and a correction of the set: multipliers
 // that turned negative leave, violated constraints enter.  A lane settles when its set
 // stood still over the last round and the point passes the KKT test of the original QP
-// (stationarity 1e-10 relative, feasibility and active-row residual 1e-12, multipliers
-// >= -1e-9 relative); rounds on an unchanged set are refinement steps, so a settled point
+// (stationarity 1e-10 relative to the larger of the gradient's terms and |H| |w|, feasibility
+// and active-row residual 1e-12, multipliers >= -1e-9 relative); rounds on an unchanged set are refinement steps, so a settled point
 // is exact to rounding.  Lanes in `skip` are left alone.  Returns true where the lane
 // settled; a lane that did not gets its controls back as they were on entry.
 __device__ __forceinline__ bool pdas(State &s, bool skip, int max_rounds, int *rounds_done = nullptr)
@@ -507,7 +507,14 @@ __device__ __forceinline__ bool pdas(State &s, bool skip, int max_rounds, int *r
 #pragma unroll
         for (int t = 0; t < TT; ++t) chk += gl[t] + ga[t] + s.ws[t];
         const bool fin = finite_d(pair_sum(chk));
-        if (!settled && !changed && fin && stat <= 1e-10 * scale && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) {
+        // Stationarity is asked relative to the gradient's terms or, where that is larger, to
+        // |H| |w|: the multiplier update lam += rho c(w) carries the rounding of the controls (an
+        // ulp, 1.1e-16 |w|) times rho = 1e5 max(diag H) into the multipliers, a floor of some
+        // 5e-11 max(diag H) |w| that no further round gets below; with a large Hessian and a small
+        // gradient the first scale alone would sit under that floor for ever.
+        // (|w| <= the box bound of the channel: the first stage's window lies inside it.)
+        const double stat_tol = 1e-10 * dmax(scale, 4e-5 * rho * pair_max(s.b_));
+        if (!settled && !changed && fin && stat <= stat_tol && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) {
             settled = true;
             accepted = true;
         }

@@ -456,7 +456,16 @@ __device__ __forceinline__ bool pdas(State<TT> &s, bool skip, int max_rounds, in
 #pragma unroll
         for (int t = 0; t < TT; ++t) chk += gl[t] + ga[t] + s.ws[t];
         const bool fin = finite_d(quad_sum(chk));
-        if (!settled && !changed && fin && stat <= 1e-10 * scale && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) {
+        // Stationarity is asked relative to the gradient's terms or, where that is larger, to
+        // |H| |w|: the multiplier update lam += rho c(w) carries the rounding of the controls (an
+        // ulp, 1.1e-16 |w|) times rho = 1e5 max(diag H) into the multipliers, a floor of some
+        // 5e-11 max(diag H) |w| that no further round gets below; with a large Hessian and a small
+        // gradient the first scale alone would sit under that floor for ever.
+        double wmax = 0.0;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) wmax = dmax(wmax, fabs(s.ws[t]));
+        const double stat_tol = 1e-10 * dmax(scale, 4e-5 * rho * quad_max(wmax));
+        if (!settled && !changed && fin && stat <= stat_tol && viol <= 1e-12 && cact <= 1e-12 && neg <= 1e-9 * scale) {
             settled = true;
             accepted = true;
         }
