@@ -223,6 +223,10 @@ __global__ __launch_bounds__(kWave) void k_solve_reg(SolveArgs a)
 #define MPCX_PAIR_K 5
 #endif
 constexpr int kPairIpmIters = MPCX_PAIR_K;   // interior-point iterations before the active-set rounds
+#ifndef MPCX_PAIR_MORE
+#define MPCX_PAIR_MORE 2
+#endif
+constexpr int kPairMoreIters = MPCX_PAIR_MORE;   // ... and the further ones of the second attempt
 #ifndef MPCX_PAIR_K10
 #define MPCX_PAIR_K10 6
 #endif

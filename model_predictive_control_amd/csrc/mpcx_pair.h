@@ -239,14 +239,61 @@ __device__ __forceinline__ void add_rate(State &s, int i, double dd)
 // after the last one) and reports MPCX_ST_FAILED unless it converged on the way; max_iter
 // may differ between lanes, the wave loops until its last lane is through.  A step that is
 // not finite (a factorisation that broke down) ends the lane's solve at the iterate it has.
-__device__ __forceinline__ void ipm(State &s, int max_iter, bool fixed, bool skip, int &status, int &iters)
+// The interior point's iterate (own controls and multipliers), kept across the active-set rounds,
+// which overwrite it, so that a second attempt can go on from it instead of starting over.
+struct Iterate {
+    // Held in accumulation registers, which this kernel has to spare (its vector registers are
+    // full): one v_accvgpr_write per 32 bits when saved, one v_accvgpr_read when taken back.
+    static constexpr int N = 3 * TT + 2 * NRT;
+    int lo[N], hi[N];
+    static __device__ __forceinline__ int to_acc(int x)
+    {
+        int a;
+        asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(x));
+        return a;
+    }
+    static __device__ __forceinline__ int from_acc(int a)
+    {
+        int x;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
+        return x;
+    }
+    __device__ __forceinline__ void put(int k, double x) { lo[k] = to_acc(__double2loint(x)); hi[k] = to_acc(__double2hiint(x)); }
+    __device__ __forceinline__ double get(int k) const { return __hiloint2double(from_acc(hi[k]), from_acc(lo[k])); }
+    __device__ __forceinline__ void save(const State &s)
+    {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) { put(t, s.ws[t]); put(TT + t, s.lamU[t]); put(2 * TT + t, s.lamL[t]); }
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) { put(3 * TT + i, s.nuU[i]); put(3 * TT + NRT + i, s.nuL[i]); }
+    }
+    __device__ __forceinline__ void restore(State &s, bool which) const
+    {
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const double w = get(t), lu = get(TT + t), ll = get(2 * TT + t);
+            s.ws[t] = which ? w : s.ws[t];
+            s.lamU[t] = which ? lu : s.lamU[t];
+            s.lamL[t] = which ? ll : s.lamL[t];
+        }
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const double nu = get(3 * TT + i), nl = get(3 * TT + NRT + i);
+            s.nuU[i] = which ? nu : s.nuU[i];
+            s.nuL[i] = which ? nl : s.nuL[i];
+        }
+    }
+};
+
+// `resume`: go on from the iterate in `s` instead of starting at the centre of the bounds.
+__device__ __forceinline__ void ipm(State &s, int max_iter, bool fixed, bool skip, int &status, int &iters, bool resume = false)
 {
     // Start: every stage at the middle of the first-stage window (strictly feasible: all
     // rate slacks equal rr).  Starting instead from the previous optimum pulled towards that
     // point lets the active set show after 3 iterations instead of 5 and lowers the mean wave
     // time by 8 %, but it makes a few waves per launch take the converged-solve fallback, and
     // the launch ends with its slowest wave: measured 114 us against 91 us, so it is not done.
-    if (!skip) {   // lanes that sit this solve out keep their controls
+    if (!skip && !resume) {   // lanes that sit this solve out keep their controls
         const double wc = 0.5 * (s.lo0 + s.hi0);
         // initial complementarity s*lambda of every constraint, in proportion to the gradient at
         // zero controls where that exceeds 1 (stage weights that grow like 2^t).  Measured on

@@ -149,30 +149,35 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
         if (pass == 0) MPCX_STAMP(1);
         // Attempt 0: a fixed, wave-uniform number of interior-point iterations, then active-set
         // rounds that either certify the exact optimum or give up.  Attempt 1 (only for lanes
-        // attempt 0 left unsettled): interior point to convergence, then the same rounds; if
-        // those do not settle either, the converged interior-point iterate is the answer.
+        // attempt 0 left unsettled; the whole wavefront waits for them, and the launch for the
+        // wavefront): kPairMoreIters further iterations from the iterate attempt 0 reached, which
+        // was kept, and the rounds again.  Attempt 2: interior point from the start to convergence,
+        // then the rounds; if those do not settle either, the converged iterate is the answer.
         bool need = !skip;
+        MPCX_PAIR_NS::Iterate keep;
 #pragma unroll 1
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < 3; ++attempt) {
             int st = MPCX_ST_OK, it = 0;
-            MPCX_PAIR_NS::ipm(s, attempt == 0 ? (a.max_iter < kFixedIters ? a.max_iter : kFixedIters) : a.max_iter, attempt == 0,
-                      !need, st, it);
-            if (pass == 0) MPCX_STAMP(2 + 2 * attempt);
+            if (attempt == 1) keep.restore(s, need);
+            const int cap = attempt == 0 ? kFixedIters : kPairMoreIters;
+            MPCX_PAIR_NS::ipm(s, attempt < 2 ? (a.max_iter < cap ? a.max_iter : cap) : a.max_iter, attempt < 2, !need, st, it, attempt == 1);
+            if (attempt == 0) keep.save(s);
+            if (pass == 0 && attempt < 2) MPCX_STAMP(2 + 2 * attempt);
             if (need) { iters += it; status = st; }
             // the rounds run even after an interior-point solve that stalled short of its
             // tolerances: they certify their own answer, and a stalled iterate usually has the set
 #ifdef MPCX_STAMPS
             int rounds = 0;
-            const bool settled = MPCX_PAIR_NS::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1, &rounds);
+            const bool settled = MPCX_PAIR_NS::pdas(s, !need, attempt < 2 ? kPairRounds0 : kPairRounds1, &rounds);
             if (pass == 0 && attempt == 0 && threadIdx.x == 0 && blockIdx.x < kStampWaves) g_stamps[blockIdx.x * kStampSlots + 7] = rounds;
 #elif defined(MPCX_DIAG)   // diagnostic builds report the rounds in the iteration count
             int rounds = 0;
-            const bool settled = MPCX_PAIR_NS::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1, &rounds);
-            if (need) iters += (attempt == 0 ? 100 : 10000) * (rounds + attempt) + (settled ? 0 : 1000000 * (attempt + 1));
+            const bool settled = MPCX_PAIR_NS::pdas(s, !need, attempt < 2 ? kPairRounds0 : kPairRounds1, &rounds);
+            if (need) iters += (attempt == 0 ? 100 : 10000) * (rounds + (attempt > 0 ? 1 : 0)) + (settled ? 0 : 1000000 * (attempt + 1));
 #else
-            const bool settled = MPCX_PAIR_NS::pdas(s, !need, attempt == 0 ? kPairRounds0 : kPairRounds1);
+            const bool settled = MPCX_PAIR_NS::pdas(s, !need, attempt < 2 ? kPairRounds0 : kPairRounds1);
 #endif
-            if (pass == 0) MPCX_STAMP(3 + 2 * attempt);
+            if (pass == 0 && attempt < 2) MPCX_STAMP(3 + 2 * attempt);
 #ifdef MPCX_TRACE_B
             if (b == MPCX_TRACE_B && live)
                 printf("b %ld lane %d pass %d attempt %d need %d ipm st %d it %d settled %d ws %g %g %g %g %g\n", (long)b,
