@@ -136,3 +136,20 @@ def test_capture_of_a_workspace_loop():
     torch.cuda.synchronize()
     assert int((loop.ticks == 2).sum().item()) == 6000
     assert (loop.out["status"].cpu().numpy() <= 1).mean() > 0.99 and float(loop.uprev.abs().sum().item()) > 0
+
+
+def test_capture_of_a_chip_resident_long_horizon_loop():
+    """A small long-horizon fleet (T = 30, 300 vehicles) goes one wavefront per instance, followed by
+    the stage-wise pass over what that leaves unsettled, which needs the workspace: captured, the pair
+    runs on the library's fixed workspace and equals the eager loop bit for bit."""
+    engine, v, ov, table, tabs, state, cid, pind = _setup("dsr_diff", 300, 35, T=30)
+    assert engine._lib.load().mpcx_workspace_bytes(engine.C.byref(v), 300) == 55 * 30 * 8 * 320
+    eager = engine.ClosedLoop(v, table, state, cid, pind0=pind).run(6)
+    graph = engine.ClosedLoop(v, table, state, cid, pind0=pind).capture()
+    graph.run(4)
+    torch.cuda.synchronize()
+    assert graph.n_done_ticks == eager.n_done_ticks == 6
+    for name in ("state", "target_ind", "done", "ticks", "has_prev"):
+        np.testing.assert_array_equal(getattr(graph, name).cpu().numpy(), getattr(eager, name).cpu().numpy())
+    np.testing.assert_array_equal(graph.last_u.cpu().numpy(), eager.last_u.cpu().numpy())
+    assert (graph.out["status"].cpu().numpy() == 0).all()
