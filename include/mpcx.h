@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MPCX_ABI_VERSION 1
+#define MPCX_ABI_VERSION 2
 
 #define MPCX_MODEL_DIFF_DRIVE 0 /* unicycle, NU = 2 (mpc_diff_drive.py:19-21) */
 #define MPCX_MODEL_DSR 1        /* dual-steer "general bicycle", NU = 4 (mpc_dsr.py:20-22) */
@@ -172,12 +172,15 @@ int mpcx_linearize_batch(const mpcx_variant *v, int64_t B, const double *theta, 
  *   outside 0..n_courses-1 and for a course whose clen is not 1..Lmax); ind_out may be the
  *   same buffer as pind (each instance reads its pind before its ind is written);
  *   mind_out [B] or NULL (signed as in mpc_diff_drive.py:116-121 when sign != 0);
- *   xref_out [B][3][T+1] or NULL. */
+ *   xref_out [B][3][T+1] or NULL;
+ *   x0_out [B][3] or NULL: x0 = [state.x, state.y, state.yaw] (mpc_diff_drive.py:363), the
+ *   first argument of the solve that follows, so that a closed loop needs no copy of its own. */
 int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int32_t n_search,
                            int32_t sign, int64_t B, const double *state, const int32_t *course_id,
                            const int32_t *pind, const double *cx, const double *cy,
                            const double *cyaw, const int32_t *clen, int64_t n_courses, int64_t Lmax,
-                           int32_t *ind_out, double *mind_out, double *xref_out, void *stream);
+                           int32_t *ind_out, double *mind_out, double *xref_out, double *x0_out,
+                           void *stream);
 
 /* What do_simulation does between two solves (mpc_diff_drive.py:363-383, mpc_dsr.py:548-571,
  * mpc_sim.py:224-247): update_state with the first control column when the solve succeeded

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPCX_LIB selects another build of the same library (kernel experiments); never a fallback
 LIB_PATH = os.environ.get("MPCX_LIB") or os.path.join(_HERE, "lib", "libmpcx.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ST_OK, ST_INACCURATE, ST_INFEASIBLE, ST_NONFINITE, ST_FAILED = 0, 1, 2, 3, 4
 MODEL_DIFF_DRIVE, MODEL_DSR = 0, 1
@@ -55,7 +55,7 @@ SIGNATURES = {
     "mpcx_linearize_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD]),
     "mpcx_nearest_ref_batch": (C.c_int, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32,
                                          C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, C.c_int64, C.c_int64,
-                                         _PD, _PD, _PD, _PD]),
+                                         _PD, _PD, _PD, _PD, _PD]),
     "mpcx_build_courses_batch": (C.c_int, [C.c_int64, C.c_int32, _PD, _PD, _PD, C.c_double, C.c_int64, C.c_int32,
                                            _PD, _PD, _PD, _PD, _PD, _PD]),
     "mpcx_advance_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, C.c_double, C.c_double, _PD, _PD, _PD, _PD,

@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_nearest_ref(int mode, int T, double dt,
                                                      const double *__restrict__ cyaw,
                                                      const int32_t *__restrict__ clen, int64_t n_courses, int64_t Lmax,
                                                      int32_t *ind_out, double *__restrict__ mind_out,
-                                                     double *__restrict__ xref_out)
+                                                     double *__restrict__ xref_out, double *__restrict__ x0_out)
 {
     const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
     const int k = threadIdx.x % kGroup;
@@ -1129,6 +1129,8 @@ __global__ __launch_bounds__(256) void k_nearest_ref(int mode, int T, double dt,
     if (len < 0 || (int64_t)len > Lmax) len = 0;
     const int pind = pind_in[b];
     const double x = state[4 * b], y = state[4 * b + 1];
+    // x0 = [state.x, state.y, state.yaw] of the solve that follows (mpc_diff_drive.py:363)
+    if (live && x0_out && k < 3) x0_out[3 * b + k] = state[4 * b + k];
     // a negative previous index (a window lost earlier) is an empty window too: never a read
     // in front of the row
     const int lo = pind < 0 ? 0 : (pind < len ? pind : len);
@@ -1762,7 +1764,7 @@ int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int
                            int64_t B, const double *state, const int32_t *course_id, const int32_t *pind,
                            const double *cx, const double *cy, const double *cyaw, const int32_t *clen,
                            int64_t n_courses, int64_t Lmax, int32_t *ind_out, double *mind_out,
-                           double *xref_out, void *stream)
+                           double *xref_out, double *x0_out, void *stream)
 {
     if (mode != 0 && mode != 1) return fail(MPCX_E_ARG, "mode must be 0 or 1");
     if (T < 1 || T > MPCX_MAX_T) return fail(MPCX_E_ARG, "horizon T=%d outside 1..%d", T, MPCX_MAX_T);
@@ -1776,7 +1778,7 @@ int mpcx_nearest_ref_batch(int32_t mode, int32_t T, double dt, double param, int
     const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     clear_stale_error();
     hipLaunchKernelGGL(k_nearest_ref, grid, block, 0, (hipStream_t)stream, mode, T, dt, param, n_search, sign, B,
-                       state, course_id, pind, cx, cy, cyaw, clen, n_courses, Lmax, ind_out, mind_out, xref_out);
+                       state, course_id, pind, cx, cy, cyaw, clen, n_courses, Lmax, ind_out, mind_out, xref_out, x0_out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : hip_fail(e, "k_nearest_ref launch");
 }

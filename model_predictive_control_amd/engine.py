@@ -220,7 +220,7 @@ def nearest_ref_batch(mode: int, T: int, dt: float, param: float, state, course_
     _lib.check(lib.mpcx_nearest_ref_batch(mode, T, dt, param, n_search, 1 if sign else 0, B, _ptr(state),
                                           _ptr(course_id), _ptr(pind), _ptr(table.cx), _ptr(table.cy),
                                           _ptr(table.cyaw), _ptr(table.clen), table.K, table.Lmax,
-                                          _ptr(ind), _ptr(mind), _ptr(xref), _stream()))
+                                          _ptr(ind), _ptr(mind), _ptr(xref), None, _stream()))
     return ind, mind, xref
 
 
@@ -280,7 +280,7 @@ class ClosedLoop:
         _lib.check(self.lib.mpcx_nearest_ref_batch(1, self.v.T, self.v.dt, float(self.n_search_ind), self.n_search, 1,
                                                    self.B, _ptr(self.state), _ptr(self.course_id), _ptr(self.target_ind),
                                                    _ptr(t.cx), _ptr(t.cy), _ptr(t.cyaw), _ptr(t.clen), t.K, t.Lmax,
-                                                   _ptr(self.target_ind), None, None, _stream()))
+                                                   _ptr(self.target_ind), None, None, None, _stream()))
         if self.log is not None:
             self.log[0].copy_(self.state)
 
@@ -291,8 +291,7 @@ class ClosedLoop:
         _lib.check(self.lib.mpcx_nearest_ref_batch(1, v.T, v.dt, float(self.n_search_ind), self.n_search, 1, self.B,
                                                    _ptr(self.state), _ptr(self.course_id), _ptr(self.target_ind),
                                                    _ptr(t.cx), _ptr(t.cy), _ptr(t.cyaw), _ptr(t.clen), t.K, t.Lmax,
-                                                   _ptr(self.target_ind), None, _ptr(self.xref), _stream()))
-        self.x0.copy_(self.state[:, :3])   # x0 = [state.x, state.y, state.yaw]
+                                                   _ptr(self.target_ind), None, _ptr(self.xref), _ptr(self.x0), _stream()))
 
     def tick(self):
         t, v, lib, st = self.table, self.v, self.lib, _stream()
@@ -466,12 +465,12 @@ class SegmentedLoop:
         self.done[idx] = 0
         self.seg_ticks[idx] = 0
 
-    def _nearest(self, pind, ind_out, xref):
+    def _nearest(self, pind, ind_out, xref, x0=None):
         t, v0 = self.table, self.variants[0]
         _lib.check(self.lib.mpcx_nearest_ref_batch(1, v0.T, v0.dt, float(self.n_search_ind), self.n_search, 1, self.B,
                                                    _ptr(self.state), _ptr(self.course_id), _ptr(pind),
                                                    _ptr(t.cx), _ptr(t.cy), _ptr(t.cyaw), _ptr(t.clen), t.K, t.Lmax,
-                                                   _ptr(ind_out), None, _ptr(xref), _stream()))
+                                                   _ptr(ind_out), None, _ptr(xref), _ptr(x0), _stream()))
 
     def _advance(self, k):
         t, v0, o = self.table, self.variants[0], self.out
@@ -486,8 +485,7 @@ class SegmentedLoop:
         if not self.device_resident:
             return self._tick_with_host_lists()
         t, lib, st, M = self.table, self.lib, _stream(), len(self.variants)
-        self._nearest(self.target_ind, self.target_ind, self.xref)
-        self.x0.copy_(self.state[:, :3])
+        self._nearest(self.target_ind, self.target_ind, self.xref, self.x0)   # x0 = [state.x, state.y, state.yaw]
         active = (self.finished == 0) & (self.done == 0)
         was_active = active.to(torch.uint8)
         mode = self.seg_mode[self.course_id.long().clamp(0, t.K - 1)]
@@ -529,8 +527,7 @@ class SegmentedLoop:
 
     def _tick_with_host_lists(self):
         t = self.table
-        self._nearest(self.target_ind, self.target_ind, self.xref)
-        self.x0.copy_(self.state[:, :3])
+        self._nearest(self.target_ind, self.target_ind, self.xref, self.x0)   # x0 = [state.x, state.y, state.yaw]
         o = self.out
         mode = self.seg_mode[self.course_id.long().clamp(0, t.K - 1)]
         active = (self.finished == 0) & (self.done == 0)

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_typed(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mpcx.h but not exported"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.mpcx_abi_version() == 1
+    assert lib.mpcx_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_struct_layout_matches_header():
@@ -76,7 +76,7 @@ def test_argument_validation_without_gpu(lib):
     vbad = variants.get("dsr_crab", nu=2)
     assert lib.mpcx_rollout_batch(C.byref(vbad), 1, None, None, None, None) == -1
     assert lib.mpcx_nearest_ref_batch(2, 5, 0.2, 2.0, 10, 1, 1, None, None, None, None, None, None, None, 1, 1,
-                                      None, None, None, None) == -1
+                                      None, None, None, None, None) == -1
 
 
 def test_chain_follows_horizon_override():

@@ -183,9 +183,16 @@ def test_bad_course_ids_and_rejected_courses_are_empty_windows(eng, golden):
     d_pind = torch.from_numpy(pind).cuda()
     d_state4 = torch.from_numpy(state).cuda()
     _lib.check(lib.mpcx_nearest_ref_batch(1, 5, 0.2, 2.0, 10, 1, B, p(d_state4), p(d_cid), p(d_pind), p(tab.cx), p(tab.cy),
-                                          p(tab.cyaw), p(tab.clen), tab.K, tab.Lmax, p(d_pind), None, None, None))
+                                          p(tab.cyaw), p(tab.clen), tab.K, tab.Lmax, p(d_pind), None, None, None, None))
     torch.cuda.synchronize()
     assert np.array_equal(d_pind.cpu().numpy(), ind)
+    # x0_out: the pose columns of the state for the solve that follows, whatever the window
+    d_x0 = torch.full((B, 3), -7.0, dtype=torch.float64, device="cuda")
+    d_pind = torch.from_numpy(pind).cuda()
+    _lib.check(lib.mpcx_nearest_ref_batch(1, 5, 0.2, 2.0, 10, 1, B, p(d_state4), p(d_cid), p(d_pind), p(tab.cx), p(tab.cy),
+                                          p(tab.cyaw), p(tab.clen), tab.K, tab.Lmax, p(d_pind), None, None, p(d_x0), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_x0.cpu().numpy(), state[:, :3], equal_nan=True)
 
 
 # ------------------------------------------------------------------------------- QP solve
