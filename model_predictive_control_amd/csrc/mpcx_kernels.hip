@@ -282,7 +282,8 @@ __host__ __device__ inline int wave_lds_doubles(int T)
     return n * (n + 1) + kWave + 11 * T + (T + 1);   // H and K (packed triangles), broadcast buffer, dynamics, yaw
 }
 
-template <int MODEL>
+// NFIX: 2T when the kernel is built for one horizon (its Cholesky then runs in registers), 0: any.
+template <int MODEL, int NFIX = 0>
 __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
 {
     extern __shared__ double smem[];
@@ -383,6 +384,83 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
             rdw[0] = v.Rd[0] + v.Rd[2]; rdw[1] = v.Rd[1] + v.Rd[3];
         }
         const double rwc = ch ? rw[1] : rw[0], rdc = ch ? rdw[1] : rdw[0];
+        if (NFIX > 0) {
+            // One horizon: lane i accumulates row i of H in registers (the entries of G of the
+            // other lanes arrive through v_readlane) and writes it to the packed triangle once.
+            // A stage updates all the columns of its half of the horizon: the lanes of later stages
+            // still hold G = 0, so the columns it does not reach receive zeros, and the stage loops
+            // stay rolled (unrolled, their LDS reads are hoisted and spill).  Slots right of the diagonal
+            // collect products that are never stored.
+            constexpr int N = NFIX > 0 ? NFIX : 2, TF = N / 2;
+            double Hrow[N];
+            {
+                double d = 2.0 * rwc;
+                if (st_own > 0) d += 2.0 * rdc;
+                if (st_own + 1 < TF) d += 2.0 * rdc;
+#pragma unroll
+                for (int k = 0; k < N; ++k) Hrow[k] = k == lane ? d : (k + 2 == lane ? -2.0 * rdc : 0.0);
+            }
+            double p[3] = {x0[0], x0[1], x0[2]}, G[3] = {0.0, 0.0, 0.0}, gacc = 0.0, qg = 1.0;
+            // stages t0 .. t1 - 1, which reach columns 0 .. KMAX - 1 at most
+            auto stages = [&](int t0, int t1, auto kmax) {
+                constexpr int KMAX = decltype(kmax)::value;
+#pragma unroll 1
+                for (int t = t0; t < t1; ++t) {
+                    volatile wave::lds_double *d = dyn + 11 * t;
+                    const double a02 = d[0], a12 = d[1];
+                    const double ct0 = d[8], ct1 = d[9], ct2 = d[10];
+                    const double pn0 = p[0] + a02 * p[2] + ct0;
+                    const double pn1 = p[1] + a12 * p[2] + ct1;
+                    const double pn2 = p[2] + ct2;
+                    p[0] = pn0; p[1] = pn1; p[2] = pn2;
+                    if (lane < 2 * t) {
+                        G[0] = fma(a02, G[2], G[0]);
+                        G[1] = fma(a12, G[2], G[1]);
+                    }
+                    if (c.act && st_own == t) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) G[r] = d[2 + 2 * r + ch];
+                    }
+                    const int ts = t + 1;
+                    double Qs[3];
+                    if (ts < TF) {
+                        qg *= v.q_growth;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) Qs[r] = v.Q[r] * qg;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) Qs[r] = v.Qf[r];
+                    }
+                    double gi[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        gi[r] = 2.0 * Qs[r] * G[r];
+                        gacc = fma(gi[r], p[r] - xr[r * W + ts], gacc);
+                    }
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        double h = Hrow[k];
+                        h = fma(gi[0], wave::bcast(G[0], k), h);
+                        h = fma(gi[1], wave::bcast(G[1], k), h);
+                        h = fma(gi[2], wave::bcast(G[2], k), h);
+                        Hrow[k] = h;
+                    }
+                }
+            };
+            constexpr int TH = TF / 2;   // the first half of the stages reaches half of the columns
+            stages(0, TH, std::integral_constant<int, 2 * TH>());
+            stages(TH, TF, std::integral_constant<int, N>());
+            {
+                int tk = 0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    if (lane >= k && c.act) c.H[tk + lane] = Hrow[k];
+                    tk += N - 1 - k;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            c.g = c.act ? gacc : 0.0;
+        } else {
         for (int e = lane; e < c.size(); e += kWave) c.H[e] = 0.0;
         __builtin_amdgcn_wave_barrier();
         if (c.act) {
@@ -449,6 +527,7 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
             __builtin_amdgcn_wave_barrier();
         }
         c.g = c.act ? gacc : 0.0;
+        }
     }
     const double hmax = wave::wmax(c.act ? c.H[c.own + lane] : 0.0);
     MPCX_STAMP(2);
@@ -466,12 +545,12 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
             int st = MPCX_ST_OK, it = 0;
             if (attempt > 0) keep.restore(c);
             const int cap = a.max_iter < kWaveIpmCap || attempt + 1 == kWaveAttempts ? a.max_iter : kWaveIpmCap;
-            wave::ipm(c, cap, kWaveSwitchMu[attempt], attempt > 0, st, it);
+            wave::ipm<NFIX>(c, cap, kWaveSwitchMu[attempt], attempt > 0, st, it);
             iters += it;
             status = st;
             keep.save(c);
             if (attempt == 0) { MPCX_STAMP(3); }
-            settled = wave::pdas(c, kWaveRounds[attempt], hmax);
+            settled = wave::pdas<NFIX>(c, kWaveRounds[attempt], hmax);
             if (attempt == 0) { MPCX_STAMP(4); }
         }
         if (settled) status = MPCX_ST_OK;
@@ -1304,14 +1383,17 @@ static int64_t stage_chunk(int64_t B)
     return B < cap ? ((B + kWave - 1) / kWave) * kWave : cap;
 }
 
-// Largest batch the wavefront-per-instance kernel takes: what the chip holds at once (256 CUs, per
-// CU as many wavefronts as LDS and registers allow, in whole wavefronts per SIMD: a fifth wavefront
-// on a CU shares a SIMD with another and doubles the launch's time).  One such round takes less than
-// the latency of a single stage-wise wavefront (measured, warm: T = 30, 1,024 instances and fewer:
-// 0.88 ms against 1.29 ms, while 1,280 take 1.80 ms against 1.43 ms; T = 12, 3,072: 0.38 ms against
-// 0.54 ms); a second round does not.
+// Largest batch the wavefront-per-instance kernel takes.  In general: what the chip holds at once
+// (256 CUs, per CU as many wavefronts as LDS and registers allow, in whole wavefronts per SIMD: a
+// fifth wavefront on a CU shares a SIMD with another and doubles the launch's time); one such round
+// takes less than the latency of a single stage-wise wavefront (measured, warm: T = 12, 3,072: 0.36 ms
+// against 0.54 ms), a second round does not.  At T = 30, where the instantiation with the Cholesky
+// in registers runs (one wavefront per SIMD, 1,024 instances in 0.50 ms), three rounds still do:
+// 3,072 instances warm 1.33 ms against 1.48 ms stage-wise (mpc_dsr.py's Q 2^t variant 2.8 against
+// 5.2 ms), 4,096 1.77 against 1.52 ms.
 static int64_t wave_batch_max(int T)
 {
+    if (T == 30) return 3 * 1024;
     const int64_t by_lds = (160 * 1024) / ((int64_t)wave_lds_doubles(T) * (int64_t)sizeof(double));
     const int64_t by_regs = 12;   // 3 wavefronts per SIMD at the kernel's register count
     int64_t per_cu = by_lds < by_regs ? by_lds : by_regs;
@@ -1477,8 +1559,13 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
         // K and H of the instance in LDS
         const size_t lds = (size_t)wave_lds_doubles(v->T) * sizeof(double);
         const dim3 wgrid((unsigned)a.B);
-        if (m == 0) hipLaunchKernelGGL((k_solve_wave<0>), wgrid, block, lds, st, a);
-        else hipLaunchKernelGGL((k_solve_wave<1>), wgrid, block, lds, st, a);
+        if (v->T == 30) {   // mpc_dsr.py's long horizon: the instantiation with the Cholesky in registers
+            if (m == 0) hipLaunchKernelGGL((k_solve_wave<0, 60>), wgrid, block, lds, st, a);
+            else hipLaunchKernelGGL((k_solve_wave<1, 60>), wgrid, block, lds, st, a);
+        } else {
+            if (m == 0) hipLaunchKernelGGL((k_solve_wave<0>), wgrid, block, lds, st, a);
+            else hipLaunchKernelGGL((k_solve_wave<1>), wgrid, block, lds, st, a);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "k_solve_wave launch");
         // About one instance in 10^5 to 10^6 of hard random controllers is left INACCURATE by this

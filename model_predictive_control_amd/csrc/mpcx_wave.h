@@ -175,6 +175,49 @@ __device__ __forceinline__ void chol(const Ctx &c)
     }
 }
 
+// The same factorisation for a horizon known at compile time (N = 2T free controls): lane i takes
+// row i of the packed K into registers, the columns are eliminated one by one there (the column's
+// entry of lane k reaches the other lanes through v_readlane, N (N - 1) / 2 of them), and the factor
+// goes back to the packed triangle for the solves.  The version above walks the matrix in LDS and is
+// bound by the round trips (157 k cycles at N = 60, three quarters of the kernel's time).
+// Entries right of the diagonal in a lane's registers are whatever the load found; they stay in
+// that lane (only entries at or below the diagonal are ever broadcast or stored).
+template <int N>
+__device__ __forceinline__ void chol_regs(const Ctx &c)
+{
+    double R[N];
+    {
+        int tk = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) { R[k] = c.K[tk + c.row]; tk += N - 1 - k; }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double r = rsqrt_nr(bcast(R[j], j));
+        const double lj = R[j] * r;              // lanes below the diagonal: L(i, j)
+        R[j] = c.lane == j ? r : lj;             // the diagonal slot keeps 1 / L_jj
+#pragma unroll
+        for (int k = j + 1; k < N; ++k) R[k] = fma(-lj, bcast(lj, k), R[k]);
+    }
+    {
+        int tk = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (c.lane >= k && c.act) c.K[tk + c.lane] = R[k];
+            tk += N - 1 - k;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// NFIX: the number of free controls when the kernel is built for one horizon (0: any).
+template <int NFIX>
+__device__ __forceinline__ void factor(const Ctx &c)
+{
+    if (NFIX > 0) chol_regs<(NFIX > 0 ? NFIX : 2)>(c);
+    else chol(c);
+}
+
 // x <- K^-1 r with the factor left by chol(); every lane passes its entry and gets its entry.
 // The factor entries of the next four columns are fetched while the chain of broadcasts works
 // through the current four.
@@ -271,6 +314,7 @@ struct Iterate {
 // can then be read off the iterate); otherwise it runs to convergence; max_iter iterations at
 // most either way.  `resume` goes on from the iterate in `c`
 // instead of starting over.  Status / iteration count are wave-uniform: one instance per wave.
+template <int NFIX>
 __device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool resume, int &status, int &iters)
 {
     const int i = c.lane;
@@ -320,7 +364,7 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool r
             status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
             return;
         }
-        chol(c);
+        factor<NFIX>(c);
         // predictor
         const double dwa = solve(c, -hw);
         const double dva = from_next(dwa, i) - dwa;
@@ -364,6 +408,7 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool r
 
 // Primal-dual active-set rounds (see pdas() of the pair kernels).  Returns true when the
 // point is certified; otherwise the controls are put back as they were.
+template <int NFIX>
 __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
 {
     const int i = c.lane;
@@ -411,7 +456,7 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
         }
         if (round >= max_rounds || !fin) break;
         MPCX_STAMP(8);
-        chol(c);
+        factor<NFIX>(c);
         MPCX_STAMP(9);
         const double step = solve(c, -(gl + ga));
         MPCX_STAMP(10);

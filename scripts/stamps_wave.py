@@ -1,4 +1,5 @@
-"""Phase timing of the wavefront-per-instance kernel from a -DMPCX_STAMPS build (MPCX_LIB points at it)."""
+"""Phase timing of the wavefront-per-instance kernel from a -DMPCX_STAMPS build (MPCX_LIB points at it).
+python scripts/stamps_wave.py [variant] [T] [B]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -6,13 +7,13 @@ from model_predictive_control_amd import engine, _lib
 from tests.helpers import make_problem
 name = sys.argv[1] if len(sys.argv) > 1 else "dsr_ackermann"
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-B = 65536
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 1024   # what the chip holds at once at T = 30
 v, ov, x0, xref = make_problem(name, B, T=T)
 for _ in range(2):
     out = engine.solve_batch(v, x0, xref)
 torch.cuda.synchronize()
 lib = _lib.load()
-n = 4096
+n = min(4096, B)
 buf = (C.c_ulonglong * (n * 16))()
 lib.mpcx_debug_stamps.restype = C.c_int
 lib.mpcx_debug_stamps.argtypes = [C.c_void_p, C.c_int]
