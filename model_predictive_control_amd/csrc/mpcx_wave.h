@@ -179,13 +179,13 @@ __device__ __forceinline__ void chol(const Ctx &c)
 // row i of the packed K into registers, the columns are eliminated one by one there (the column's
 // entry of lane k reaches the other lanes through v_readlane, N (N - 1) / 2 of them), and the factor
 // goes back to the packed triangle for the solves.  The version above walks the matrix in LDS and is
-// bound by the round trips (157 k cycles at N = 60, three quarters of the kernel's time).
+// bound by the round trips (157 k cycles at N = 60, three quarters of the kernel's time; this one
+// 46 k; sending the column through LDS and reading it back as broadcasts instead: 78 k).
 // Entries right of the diagonal in a lane's registers are whatever the load found; they stay in
 // that lane (only entries at or below the diagonal are ever broadcast or stored).
 template <int N>
-__device__ __forceinline__ void chol_regs(const Ctx &c)
+__device__ __forceinline__ void chol_regs(const Ctx &c, double (&R)[N])
 {
-    double R[N];
     {
         int tk = 0;
 #pragma unroll
@@ -210,21 +210,25 @@ __device__ __forceinline__ void chol_regs(const Ctx &c)
     __builtin_amdgcn_wave_barrier();
 }
 
-// NFIX: the number of free controls when the kernel is built for one horizon (0: any).
+// NFIX: the number of free controls when the kernel is built for one horizon (0: any).  The
+// factor's rows then stay in registers for the forward substitutions that follow.
 template <int NFIX>
-__device__ __forceinline__ void factor(const Ctx &c)
+struct Factor {
+    double R[NFIX > 0 ? NFIX : 1];
+};
+template <int NFIX>
+__device__ __forceinline__ void factor(const Ctx &c, Factor<NFIX> &F)
 {
-    if (NFIX > 0) chol_regs<(NFIX > 0 ? NFIX : 2)>(c);
+    if constexpr (NFIX > 0) chol_regs<NFIX>(c, F.R);
     else chol(c);
 }
 
 // x <- K^-1 r with the factor left by chol(); every lane passes its entry and gets its entry.
 // The factor entries of the next four columns are fetched while the chain of broadcasts works
 // through the current four.
-__device__ __forceinline__ double solve(const Ctx &c, double r)
+__device__ __forceinline__ double solve_forward(const Ctx &c, double acc)
 {
     const int n = c.n, i = c.lane;
-    double acc = c.act ? r : 0.0;
     const int row = c.row;
     const int n4 = n & ~3;
     double dj[4], lij[4], djn[4], lijn[4];
@@ -255,6 +259,15 @@ __device__ __forceinline__ double solve(const Ctx &c, double r)
         if (i == j) acc = yj;
         else if (i > j && i < n) acc = fma(-(q == 0 ? lij[0] : lij[1]), yj, acc);
     }
+    return acc;
+}
+
+__device__ __forceinline__ double solve_backward(const Ctx &c, double acc)
+{
+    const int n = c.n, i = c.lane;
+    const int row = c.row;
+    double dj[4], lij[4], djn[4], lijn[4];
+    int j;
     // backward: L' z = y, row by row of L (the lane walks down its own column)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -283,6 +296,25 @@ __device__ __forceinline__ double solve(const Ctx &c, double r)
         else if (i < j) acc = fma(-(q == 0 ? lij[0] : lij[1]), zj, acc);
     }
     return acc;
+}
+
+// x <- K^-1 r.  With the factor's rows in registers the forward substitution needs no LDS: lane j
+// scales its entry by 1 / L_jj (its diagonal slot), one v_readlane pair hands it to the lanes below.
+// The backward substitution walks columns, which only the packed triangle in LDS offers.
+template <int NFIX>
+__device__ __forceinline__ double solve(const Ctx &c, const Factor<NFIX> &F, double r)
+{
+    double acc = c.act ? r : 0.0;
+    if constexpr (NFIX > 0) {
+#pragma unroll
+        for (int j = 0; j < NFIX; ++j) {
+            const double yj = bcast(acc * F.R[j], j);
+            acc = c.lane == j ? yj : (c.lane > j && c.act ? fma(-F.R[j], yj, acc) : acc);
+        }
+    } else {
+        acc = solve_forward(c, acc);
+    }
+    return solve_backward(c, acc);
 }
 
 // K diagonal and same-channel sub-diagonal terms: `db` on the lane's own diagonal entry, `dr`
@@ -338,6 +370,7 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool r
     }
     status = MPCX_ST_FAILED;
     iters = 0;
+    Factor<NFIX> F;
     for (int it = 0;; ++it) {
         const double hw = matvec<true>(c, c.w);
         // slacks, barrier terms
@@ -364,9 +397,9 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool r
             status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
             return;
         }
-        factor<NFIX>(c);
+        factor<NFIX>(c, F);
         // predictor
-        const double dwa = solve(c, -hw);
+        const double dwa = solve<NFIX>(c, F, -hw);
         const double dva = from_next(dwa, i) - dwa;
         const double xu = dwa * isu, xl = -dwa * isl, yu = dva * iru, yl = -dva * irl;
         double rp = 0.0, rdm = 1.0;
@@ -381,7 +414,7 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool r
         const double ql = c.hb ? fma(sm, isl, c.lamL * xl * (xl - 1.0)) : 0.0;
         const double pu = c.hr ? fma(sm, iru, c.nuU * yu * (yu - 1.0)) : 0.0;
         const double pl = c.hr ? fma(sm, irl, c.nuL * yl * (yl - 1.0)) : 0.0;
-        const double dw = dwa + solve(c, -ct_apply(c, qu - ql, pu - pl));
+        const double dw = dwa + solve<NFIX>(c, F, -ct_apply(c, qu - ql, pu - pl));
         const double dvv = from_next(dw, i) - dw;
         const double zu = dw * isu, zl = -dw * isl, vu = dvv * iru, vl = -dvv * irl;
         const double dlu = fma(c.lamU, zu, qu - c.lamU), dll = fma(c.lamL, zl, ql - c.lamL);
@@ -423,6 +456,7 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
         c.nuU = bu ? c.nuU : 0.0; c.nuL = bl ? c.nuL : 0.0;
     }
     bool changed = true, accepted = false, eased = false;
+    Factor<NFIX> F;
     for (int round = 0;; ++round) {
         const double hw = matvec<true>(c, c.w);
         const double dv = from_next(c.w, i) - c.w;
@@ -456,9 +490,9 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
         }
         if (round >= max_rounds || !fin) break;
         MPCX_STAMP(8);
-        factor<NFIX>(c);
+        factor<NFIX>(c, F);
         MPCX_STAMP(9);
-        const double step = solve(c, -(gl + ga));
+        const double step = solve<NFIX>(c, F, -(gl + ga));
         MPCX_STAMP(10);
 #ifdef MPCX_STAMPS
         if (threadIdx.x == 0 && blockIdx.x < kStampWaves) g_stamps[blockIdx.x * kStampSlots + 7] += 1;
