@@ -13,6 +13,8 @@ for seed in map(int, sys.argv[1:]):
     kw = _random_overrides(rng, base)
     B = int(rng.choice([1, 7, 64, 65, 130, 1200, 3500]))
     B = int(os.environ.get("FUZZ_B", B))      # e.g. FUZZ_B=32768: rare lanes need large batches to show
+    if "FUZZ_T" in os.environ:                 # e.g. FUZZ_T=30: the horizon the generator does not draw
+        kw["T"] = int(os.environ["FUZZ_T"])
     v, ov, x0, xref = make_problem(base, B, seed=50 + seed, **kw)
     T = ov.T
     print("seed", seed, base, "T", T, "B", B, "chain", ov.chain, {k: kw[k] for k in ("dt", "q_growth") if k in kw})

@@ -63,3 +63,31 @@ def test_unsettled_instances_are_solved_again(seed):
     fixed = engine.solve_batch(v, engine._dev(x0), engine._dev(xref), engine._dev(up), None, out=out, noalloc=True)
     for k in ("u", "x", "obj", "status"):
         assert torch.equal(fixed[k], warm[k]), k
+
+
+def test_mpc_dsr_horizon_30_small_batch_against_the_arbiter():
+    """mpc_dsr.py's T = 30 variant (Q 2^t, cond(H) about 5e10) on the wavefront-per-instance kernel
+    (1,024 instances: its fixed-horizon instantiation): where engine and oracle are more than 1e-5
+    apart, the engine has to be within the 1e-3 bar of the extended-precision minimiser of the
+    reference's (x, u) programme, and the objectives within 1e-4 relative everywhere."""
+    from model_predictive_control_amd import engine
+    from tests.helpers import OBJ_BAR, U_BAR
+    from tests.test_gpu_full_size import _settle_with_the_arbiter
+    B, T = 1024, 30
+    v, ov, x0, xref = make_problem("dsr_diff", B, seed=37, n_courses=64, T=T)
+    assert engine._lib.load().mpcx_workspace_bytes(engine.C.byref(v), B) == 55 * T * 8 * B   # the route with the second pass
+    ref = orc.iterative_batch(ov, x0, xref, None, None, nthreads=8)
+    out = engine.solve_batch(v, x0, xref)
+    up = out["u"].cpu().numpy()
+    ref2 = orc.iterative_batch(ov, x0, xref, up, None, nthreads=8)
+    out2 = engine.solve_batch(v, x0, xref, up)
+    ucold = np.tile(np.tile(np.asarray(ov.cold_start, float)[:ov.nu, None], (1, T))[None], (B, 1, 1))
+    for o, r, ur in ((out, ref, ucold), (out2, ref2, up)):
+        g = {k: o[k].cpu().numpy() for k in ("u", "x", "obj", "status")}
+        assert (g["status"] == 0).all()
+        both = r["status"] <= 1
+        assert (np.abs(g["obj"][both] - r["obj"][both]) / np.maximum(1.0, np.abs(r["obj"][both]))).max() <= OBJ_BAR
+        du = np.abs(g["u"] - r["u"]).reshape(B, -1).max(1)
+        far = np.flatnonzero(both & (du > 1e-5))
+        d_gpu, d_ref = _settle_with_the_arbiter("dsr_diff", T, v, x0, xref, ur, g, r, far)
+        assert d_gpu.max(initial=0.0) <= U_BAR, (d_gpu.max(), d_ref.max())
