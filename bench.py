@@ -184,7 +184,8 @@ def other_configs(steps: int = 3):
     (inputs resident; "warm" = linearised at their own cold optimum, as the reference's loop
     feeds the previous answer back): 65,536 and 262,144 diff-drive T=5, 65,536 mpc.py T=10, and mpc_dsr.py
     at T=30 both ways: the QP its iterative_linear_mpc_control actually calls (fixed steer, stage
-    weights Q 2^t, mpc_dsr.py:193,349) and the ackermann one."""
+    weights Q 2^t, mpc_dsr.py:193,349) and the ackermann one, at 65,536 instances (throughput) and at
+    1,024 and 1 (latency: what a small fleet or the reference's single vehicle waits per solve)."""
     import torch
     from model_predictive_control_amd import engine, variants, workload
     res = []
@@ -195,7 +196,10 @@ def other_configs(steps: int = 3):
                                ("mpc_py", 65536, None, "k_solve_quad<dual-steer, T=10> (four lanes per instance)"),
                                ("mpc_py", 32768, None, "k_solve_quad<dual-steer, T=10> (four lanes per instance)"),
                                ("dsr_diff", 65536, 30, "k_solve_stage<dual-steer>"),
-                               ("dsr_ackermann", 65536, 30, "k_solve_stage<dual-steer>")):
+                               ("dsr_ackermann", 65536, 30, "k_solve_stage<dual-steer>"),
+                               ("dsr_diff", 1024, 30, "k_solve_wave<dual-steer, T=30> (one wavefront per instance) + k_solve_stage<REDO>"),
+                               ("dsr_ackermann", 1024, 30, "k_solve_wave<dual-steer, T=30> (one wavefront per instance) + k_solve_stage<REDO>"),
+                               ("dsr_diff", 1, 30, "k_solve_wave<dual-steer, T=30> (one wavefront per instance) + k_solve_stage<REDO>")):
         v = variants.get(name, T=T) if T else variants.get(name)
         inst = workload.make_instances(courses, B, seed=2003)
         window = workload.reference_window_next_points if name == "mpc_py" else workload.reference_window
@@ -207,7 +211,7 @@ def other_configs(steps: int = 3):
         for start, u in (("cold", None), ("warm", up)):
             if start == "cold" and T != 30:
                 continue
-            n = steps if v.T > 10 else 40 * steps      # the short kernels need more launches for a stable figure
+            n = steps if v.T > 10 and B > 4096 else 40 * steps      # the short kernels need more launches for a stable figure
             for _ in range(max(1, n // 4)):
                 engine.solve_batch(v, d_x0, d_xref, u, out=out)
             torch.cuda.synchronize()
