@@ -121,6 +121,38 @@ int mpcx_solve_range_batch(const mpcx_variant *v, int64_t B, const int32_t *rang
                            const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,
                            double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream);
 
+/* The same dispatch for a whole fleet in one launch: the batch is sorted by mode, run m (instances
+ * bounds[m] .. bounds[m+1]-1, the n_modes + 1 bounds read from DEVICE memory when the kernel runs) is
+ * solved with variants[m]; instances outside every run are neither read nor written.  Every run gets
+ * wavefronts of its own, so one launch fills the chip where one mpcx_solve_range_batch call per mode
+ * fills a part of it after the other.  variants: host array (validated here); variants_dev: the same
+ * array in device memory (uploaded once by the caller; the kernel reads each run's variant from it).
+ * The modes share model, horizon and chain length; T = 5 with every bound present and the
+ * dual-steer model (every mpc_sim mode), MPCX_E_UNSUPPORTED otherwise. */
+int mpcx_solve_modes_batch(const mpcx_variant *variants, int32_t n_modes, const mpcx_variant *variants_dev,
+                           const int32_t *bounds, int64_t B, const double *x0, const double *xref,
+                           const double *uprev, const uint8_t *has_prev, double *u_out, double *x_out,
+                           double *obj_out, int32_t *status_out, int32_t *iters_out, void *stream);
+
+/* The fleet side of that dispatch, on the device: a stable counting sort of B vehicles by the mode
+ * of their current course-table row (seg_mode [n_courses], values 0..n_modes-1; a vehicle with
+ * finished != 0 or done != 0 is at rest and sorts last), and the solve's inputs gathered in that order.
+ *   was_active [B] (1 = the vehicle takes part in this tick);  order [B]: vehicle of every sorted row;
+ *   bounds [n_modes + 2]: start of every mode's run, start of the vehicles at rest, B (the first
+ *   n_modes + 1 entries are what mpcx_solve_modes_batch takes);  x0 / xref / uprev (any may be NULL)
+ *   -> *_sorted, has_prev (NULL = all 1) -> has_prev_sorted;  scratch: mpcx_mode_sort_scratch_ints()
+ *   int32 of device memory (MPCX_E_UNSUPPORTED beyond about 3 million vehicles in 3 modes; at most 7
+ *   modes).  mpcx_mode_unsort_batch carries the controls and statuses back: row p of the sorted
+ *   arrays to vehicle order[p]. */
+int64_t mpcx_mode_sort_scratch_ints(int64_t B, int32_t n_modes);
+int mpcx_mode_sort_batch(int64_t B, int32_t n_modes, int32_t nu, int32_t T, const uint8_t *finished, const uint8_t *done,
+                         const int32_t *course_id, const int32_t *seg_mode, int64_t n_courses, const double *x0,
+                         const double *xref, const double *uprev, const uint8_t *has_prev, uint8_t *was_active,
+                         int32_t *order, int32_t *bounds, double *x0_sorted, double *xref_sorted, double *uprev_sorted,
+                         uint8_t *has_prev_sorted, int32_t *scratch, void *stream);
+int mpcx_mode_unsort_batch(int64_t B, int32_t nu, int32_t T, const int32_t *order, const double *u_sorted,
+                           const int32_t *status_sorted, double *u, int32_t *status, void *stream);
+
 /* No counterpart in the reference: mpcx_solve_batch for callers that cannot allocate device
  * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
  * Same arguments, same kernels, same results; the call itself allocates and frees nothing,

@@ -48,6 +48,11 @@ SIGNATURES = {
     "mpcx_solve_batch_noalloc": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
     "mpcx_static_workspace_bytes": (C.c_int64, []),
     "mpcx_solve_range_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
+    "mpcx_solve_modes_batch": (C.c_int, [_PD, C.c_int32, _PD, _PD, C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
+    "mpcx_mode_sort_scratch_ints": (C.c_int64, [C.c_int64, C.c_int32]),
+    "mpcx_mode_sort_batch": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, C.c_int64, _PD, _PD, _PD, _PD,
+                                       _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),
+    "mpcx_mode_unsort_batch": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PD]),
     "mpcx_segment_step_batch": (C.c_int, [C.c_int64, C.c_int32, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD,
                                           C.c_int64, C.c_int64, _PD, _PD, _PD, _PD]),
     "mpcx_linear_mpc_batch": (C.c_int, [C.POINTER(CVariant), C.c_int64, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD, _PD]),

@@ -47,7 +47,10 @@ struct SolveArgs {
     int32_t *status_out, *iters_out;
     int32_t linear_mode;   // 1: (xbar, uref) given -> one QP;  0: cold start + rollout (+ chain)
     int32_t max_iter;
-    const int32_t *range;  // device memory, {first, end}: only these instances are solved (nullptr: all)
+    const int32_t *range;  // device memory, {first, end}: only these instances are solved (nullptr: all);
+                           // with vtab: n_modes + 1 bounds of the runs of a batch sorted by mode
+    const mpcx_variant *vtab;   // device memory: the variant of every run (nullptr: one variant, v)
+    int32_t n_modes;
 };
 
 // STORED: the linearisation point lives in the store (chained mpc_sim solves, and the
@@ -1182,6 +1185,139 @@ __global__ __launch_bounds__(256) void k_segment_step(int64_t B, int cap, const 
 }
 
 // ------------------------------------------------------------------------------------
+// A fleet sorted by motion mode (MPC.iterativeLMPC's dispatch on `mode`, mpc_sim.py:301-306, for
+// many vehicles): a stable counting sort by key = the mode of the vehicle's current table row, or
+// n_modes for a vehicle at rest, in three small kernels (per-block counts, one-block scan, ranks
+// and gather), and the way back for the answers.  kSortBlock vehicles per block.
+// ------------------------------------------------------------------------------------
+constexpr int kSortBlock = 1024, kSortMaxKeys = 8, kSortScanMax = 12288;
+
+__device__ __forceinline__ int sort_key(int64_t b, int64_t B, int n_modes, const uint8_t *finished, const uint8_t *done,
+                                        const int32_t *course_id, const int32_t *seg_mode, int64_t n_courses)
+{
+    if (b >= B) return -1;
+    if (finished[b] != 0 || done[b] != 0) return n_modes;
+    int64_t c = course_id[b];
+    c = c < 0 ? 0 : (c >= n_courses ? n_courses - 1 : c);
+    const int m = seg_mode[c];
+    return m < 0 || m >= n_modes ? n_modes : m;
+}
+
+__global__ __launch_bounds__(kSortBlock) void k_mode_count(int64_t B, int n_modes, const uint8_t *__restrict__ finished,
+                                                           const uint8_t *__restrict__ done, const int32_t *__restrict__ course_id,
+                                                           const int32_t *__restrict__ seg_mode, int64_t n_courses,
+                                                           uint8_t *__restrict__ was_active, int32_t *__restrict__ counts)
+{
+    __shared__ int cnt[kSortMaxKeys];
+    if (threadIdx.x < kSortMaxKeys) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * kSortBlock + threadIdx.x;
+    const int key = sort_key(b, B, n_modes, finished, done, course_id, seg_mode, n_courses);
+    if (b < B) was_active[b] = key < n_modes ? 1 : 0;
+    for (int m = 0; m <= n_modes; ++m) {
+        const unsigned long long mask = __ballot(key == m);
+        if ((threadIdx.x & (kWave - 1)) == 0 && mask) atomicAdd(&cnt[m], __popcll(mask));
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= n_modes) counts[(int64_t)blockIdx.x * (n_modes + 1) + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// counts [nblocks][n_modes + 1] -> in place: start of (block, key) in the sorted order; bounds
+// [n_modes + 2]: start of every key's run and B.
+__global__ __launch_bounds__(256) void k_mode_scan(int nblocks, int n_modes, int32_t *__restrict__ counts,
+                                                   int32_t *__restrict__ bounds)
+{
+    __shared__ int buf[kSortScanMax];
+    __shared__ int total[kSortMaxKeys + 1];
+    const int nk = n_modes + 1, n = nblocks * nk;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) buf[i] = counts[i];
+    __syncthreads();
+    if ((int)threadIdx.x < nk) {      // one thread per key walks the blocks
+        int run = 0;
+        for (int blk = 0; blk < nblocks; ++blk) {
+            const int c = buf[blk * nk + threadIdx.x];
+            buf[blk * nk + threadIdx.x] = run;
+            run += c;
+        }
+        total[threadIdx.x] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int m = 0; m < nk; ++m) { const int c = total[m]; total[m] = run; bounds[m] = run; run += c; }
+        bounds[nk] = run;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) counts[i] = buf[i] + total[i % nk];
+}
+
+// Position of every vehicle in the sorted order (stable: by vehicle index inside a key), the
+// permutation, and the solve's inputs gathered into that order, record by record.
+__global__ __launch_bounds__(kSortBlock) void k_mode_gather(int64_t B, int n_modes, const uint8_t *__restrict__ finished,
+                                                            const uint8_t *__restrict__ done, const int32_t *__restrict__ course_id,
+                                                            const int32_t *__restrict__ seg_mode, int64_t n_courses,
+                                                            const int32_t *__restrict__ starts, int32_t *__restrict__ order,
+                                                            int n0, const double *__restrict__ x0, double *__restrict__ x0_s,
+                                                            int n1, const double *__restrict__ xref, double *__restrict__ xref_s,
+                                                            int n2, const double *__restrict__ up, double *__restrict__ up_s,
+                                                            const uint8_t *__restrict__ hp, uint8_t *__restrict__ hp_s)
+{
+    constexpr int kWaves = kSortBlock / kWave;
+    __shared__ int wcnt[kWaves][kSortMaxKeys];
+    __shared__ int pos[kSortBlock];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int64_t base = (int64_t)blockIdx.x * kSortBlock, b = base + threadIdx.x;
+    const int key = sort_key(b, B, n_modes, finished, done, course_id, seg_mode, n_courses);
+    int rank = 0;
+    for (int m = 0; m <= n_modes; ++m) {
+        const unsigned long long mask = __ballot(key == m);
+        if (key == m) rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[wave][m] = __popcll(mask);
+    }
+    __syncthreads();
+    int p = -1;
+    if (key >= 0) {
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += wcnt[w][key];
+        p = starts[(int64_t)blockIdx.x * (n_modes + 1) + key] + before + rank;
+        order[p] = (int32_t)b;
+        hp_s[p] = hp ? hp[b] : 1;
+    }
+    pos[threadIdx.x] = p;
+    __syncthreads();
+    const int64_t live = B - base < kSortBlock ? B - base : kSortBlock;
+    auto copy = [&](int per, const double *__restrict__ src, double *__restrict__ dst) {
+        if (!src) return;
+        const int64_t n = live * per;
+        for (int64_t e = threadIdx.x; e < n; e += kSortBlock) {
+            const int r = (int)(e / per), j = (int)(e % per);
+            dst[(int64_t)pos[r] * per + j] = src[(base + r) * per + j];
+        }
+    };
+    copy(n0, x0, x0_s);
+    copy(n1, xref, xref_s);
+    copy(n2, up, up_s);
+}
+
+// The answers back in the fleet's order: row p of the sorted arrays belongs to vehicle order[p].
+__global__ __launch_bounds__(kSortBlock) void k_mode_scatter(int64_t B, const int32_t *__restrict__ order, int per,
+                                                             const double *__restrict__ u_s, double *__restrict__ u,
+                                                             const int32_t *__restrict__ status_s, int32_t *__restrict__ status)
+{
+    __shared__ int who[kSortBlock];
+    const int64_t base = (int64_t)blockIdx.x * kSortBlock, p = base + threadIdx.x;
+    who[threadIdx.x] = p < B ? order[p] : -1;
+    if (p < B) status[who[threadIdx.x]] = status_s[p];
+    __syncthreads();
+    const int64_t live = B - base < kSortBlock ? B - base : kSortBlock;
+    const int64_t n = live * per;
+    for (int64_t e = threadIdx.x; e < n; e += kSortBlock) {
+        const int r = (int)(e / per), j = (int)(e % per);
+        u[(int64_t)who[r] * per + j] = u_s[(base + r) * per + j];
+    }
+}
+
+// ------------------------------------------------------------------------------------
 constexpr int kGroup = 16;
 
 __global__ __launch_bounds__(256) void k_nearest_ref(int mode, int T, double dt, double param, int n_search,
@@ -1494,18 +1630,24 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
     clear_stale_error();
     const int m = v->model == MPCX_MODEL_DIFF_DRIVE ? 0 : 1;
     bool redo = false;
-    if (a.range && choose_path(v, a.B, chained) != kPathPair5)
+    if ((a.range || a.vtab) && choose_path(v, a.B, chained) != kPathPair5)
         return fail(MPCX_E_UNSUPPORTED, "a device-resident instance range is taken by the T = 5 lane-pair kernel only");
     switch (choose_path(v, a.B, chained)) {
     case kPathPair5: {
         const dim3 pgrid((unsigned)((2 * a.B + kWave - 1) / kWave));
-        if (a.range) {
+        if (a.vtab) {
+            // every run of the mode-sorted batch starts a wavefront of its own
+            const dim3 mgrid(pgrid.x + (unsigned)a.n_modes);
+            if (m == 0) return fail(MPCX_E_UNSUPPORTED, "a batch sorted by mode is taken for the dual-steer model only");
+            if (chained) hipLaunchKernelGGL((k_solve_pair5<1, true, 2>), mgrid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_solve_pair5<1, false, 2>), mgrid, block, 0, st, a);
+        } else if (a.range) {
             if (m == 0) {
-                if (chained) hipLaunchKernelGGL((k_solve_pair5<0, true, true>), pgrid, block, 0, st, a);
-                else hipLaunchKernelGGL((k_solve_pair5<0, false, true>), pgrid, block, 0, st, a);
+                if (chained) hipLaunchKernelGGL((k_solve_pair5<0, true, 1>), pgrid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_solve_pair5<0, false, 1>), pgrid, block, 0, st, a);
             } else {
-                if (chained) hipLaunchKernelGGL((k_solve_pair5<1, true, true>), pgrid, block, 0, st, a);
-                else hipLaunchKernelGGL((k_solve_pair5<1, false, true>), pgrid, block, 0, st, a);
+                if (chained) hipLaunchKernelGGL((k_solve_pair5<1, true, 1>), pgrid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_solve_pair5<1, false, 1>), pgrid, block, 0, st, a);
             }
         } else if (m == 0) {
             if (chained) hipLaunchKernelGGL((k_solve_pair5<0, true>), pgrid, block, 0, st, a);
@@ -1747,6 +1889,88 @@ int mpcx_solve_range_batch(const mpcx_variant *v, int64_t B, const int32_t *rang
     a.max_iter = 60;
     a.range = range;
     return launch_solve(a, (hipStream_t)stream);
+}
+
+int mpcx_solve_modes_batch(const mpcx_variant *variants, int32_t n_modes, const mpcx_variant *variants_dev,
+                           const int32_t *bounds, int64_t B, const double *x0, const double *xref, const double *uprev,
+                           const uint8_t *has_prev, double *u_out, double *x_out, double *obj_out, int32_t *status_out,
+                           int32_t *iters_out, void *stream)
+{
+    if (!variants || n_modes < 1 || n_modes > 16) return fail(MPCX_E_ARG, "1..16 modes");
+    for (int32_t m = 0; m < n_modes; ++m) {
+        if (int rc = check_variant(&variants[m])) return rc;
+        const mpcx_variant &a = variants[0], &b = variants[m];
+        if (a.model != b.model || a.nu != b.nu || a.T != b.T || (a.chain > 1) != (b.chain > 1) ||
+            (a.chain > 1 && a.chain != b.chain))
+            return fail(MPCX_E_ARG, "the modes of one launch share model, horizon and chain length");
+        if (!uses_registers(&b))
+            return fail(MPCX_E_UNSUPPORTED, "a batch sorted by mode is taken by the T = 5 lane-pair kernel only");
+    }
+    if (B < 0 || B > 2147483647LL) return fail(MPCX_E_ARG, "batch outside 0..2^31-1");
+    if (!variants_dev || !bounds) return fail(MPCX_E_ARG, "variants_dev / bounds is NULL");
+    if (B > 0 && (!x0 || !xref || !u_out || !x_out || !obj_out || !status_out))
+        return fail(MPCX_E_ARG, "NULL buffer");
+    SolveArgs a;
+    memset(&a, 0, sizeof(a));
+    a.v = variants[0]; a.B = B; a.x0 = x0; a.xref = xref; a.xbar = nullptr; a.uin = uprev; a.has_prev = has_prev;
+    a.u_out = u_out; a.x_out = x_out; a.obj_out = obj_out; a.status_out = status_out; a.iters_out = iters_out;
+    a.linear_mode = 0;
+    a.max_iter = 60;
+    a.range = bounds;
+    a.vtab = variants_dev;
+    a.n_modes = n_modes;
+    return launch_solve(a, (hipStream_t)stream);
+}
+
+int64_t mpcx_mode_sort_scratch_ints(int64_t B, int32_t n_modes)
+{
+    if (B < 0 || n_modes < 1 || n_modes + 1 > kSortMaxKeys) return MPCX_E_ARG;
+    const int64_t nblocks = (B + kSortBlock - 1) / kSortBlock;
+    if (nblocks * (n_modes + 1) > kSortScanMax) return MPCX_E_UNSUPPORTED;
+    return nblocks * (n_modes + 1);
+}
+
+int mpcx_mode_sort_batch(int64_t B, int32_t n_modes, int32_t nu, int32_t T, const uint8_t *finished, const uint8_t *done,
+                         const int32_t *course_id, const int32_t *seg_mode, int64_t n_courses, const double *x0,
+                         const double *xref, const double *uprev, const uint8_t *has_prev, uint8_t *was_active,
+                         int32_t *order, int32_t *bounds, double *x0_sorted, double *xref_sorted, double *uprev_sorted,
+                         uint8_t *has_prev_sorted, int32_t *scratch, void *stream)
+{
+    if (B < 0 || n_modes < 1 || n_modes + 1 > kSortMaxKeys || n_courses < 1 || nu < 1 || T < 1)
+        return fail(MPCX_E_ARG, "bad sizes (at most %d modes)", kSortMaxKeys - 1);
+    const int64_t nblocks = (B + kSortBlock - 1) / kSortBlock;
+    if (nblocks * (n_modes + 1) > kSortScanMax)
+        return fail(MPCX_E_UNSUPPORTED, "a fleet of %lld vehicles in %d modes is beyond the one-block scan", (long long)B, n_modes);
+    if (!finished || !done || !course_id || !seg_mode || !was_active || !order || !bounds || !has_prev_sorted || !scratch ||
+        (x0 && !x0_sorted) || (xref && !xref_sorted) || (uprev && !uprev_sorted))
+        return fail(MPCX_E_ARG, "NULL buffer");
+    hipStream_t st = (hipStream_t)stream;
+    clear_stale_error();
+    if (B > 0) {
+        hipLaunchKernelGGL(k_mode_count, dim3((unsigned)nblocks), dim3(kSortBlock), 0, st, B, (int)n_modes, finished, done, course_id,
+                           seg_mode, n_courses, was_active, scratch);
+    }
+    hipLaunchKernelGGL(k_mode_scan, dim3(1), dim3(256), 0, st, (int)nblocks, (int)n_modes, scratch, bounds);
+    if (B > 0) {
+        hipLaunchKernelGGL(k_mode_gather, dim3((unsigned)nblocks), dim3(kSortBlock), 0, st, B, (int)n_modes, finished, done,
+                           course_id, seg_mode, n_courses, (const int32_t *)scratch, order, 3, x0, x0_sorted, 3 * (T + 1), xref,
+                           xref_sorted, nu * T, uprev, uprev_sorted, has_prev, has_prev_sorted);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "mode sort launch");
+}
+
+int mpcx_mode_unsort_batch(int64_t B, int32_t nu, int32_t T, const int32_t *order, const double *u_sorted,
+                           const int32_t *status_sorted, double *u, int32_t *status, void *stream)
+{
+    if (B < 0 || nu < 1 || T < 1) return fail(MPCX_E_ARG, "bad sizes");
+    if (B == 0) return 0;
+    if (!order || !u_sorted || !status_sorted || !u || !status) return fail(MPCX_E_ARG, "NULL buffer");
+    clear_stale_error();
+    hipLaunchKernelGGL(k_mode_scatter, dim3((unsigned)((B + kSortBlock - 1) / kSortBlock)), dim3(kSortBlock), 0, (hipStream_t)stream,
+                       B, order, (int)(nu * T), u_sorted, u, status_sorted, status);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : hip_fail(e, "k_mode_scatter launch");
 }
 
 int mpcx_segment_step_batch(int64_t B, int32_t max_ticks_per_segment, const uint8_t *was_active, const int32_t *seg_start,

@@ -4,8 +4,10 @@
 namespace mpcx {
 
 // CHAIN: the MPC.iterativeLMPC flavour (T chained QPs per call); otherwise exactly one QP.
-// RANGE: only the instances a.range[0] .. a.range[1]-1 (bounds in device memory) are solved.
-template <int MODEL, bool CHAIN, bool RANGE = false>
+// RANGE 1: only the instances a.range[0] .. a.range[1]-1 (bounds in device memory) are solved.
+// RANGE 2: the batch is sorted by mode; run m, instances a.range[m] .. a.range[m+1]-1, is solved
+// with the variant a.vtab[m] (device memory), every run by wavefronts of its own.
+template <int MODEL, bool CHAIN, int RANGE = 0>
 __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveArgs a)
 {
     // LDS: Hs = input staging (x0, controls, xbar), then H and g, then output staging;
@@ -24,20 +26,36 @@ __global__ __launch_bounds__(kWave, MPCX_PAIR_OCC) void MPCX_PAIR_KERNEL(SolveAr
     constexpr int SX = MPCX_PAIR_NS::padded(3 * W), SU = MPCX_PAIR_NS::padded(NU * T), S0 = MPCX_PAIR_NS::padded(3);   // record strides in LDS
     constexpr int kInU = MPCX_PAIR_NS::kPairs * S0, kInXbar = kInU + MPCX_PAIR_NS::kPairs * SU;
     static_assert(kInXbar + MPCX_PAIR_NS::kPairs * SX <= MPCX_PAIR_NS::kLdsPerLane * kWave, "input staging must fit in the H area");
-    const mpcx_variant &v = a.v;
     MPCX_PAIR_NS::State s;
     const int lane = threadIdx.x;
     MPCX_STAMP_CLEAR();
     MPCX_STAMP(0);
     s.bind((MPCX_PAIR_NS::lds_double *)Hs, (MPCX_PAIR_NS::lds_double *)(kAliasDyn ? Hs : Ds), lane);
-    const int64_t b0 = (int64_t)blockIdx.x * MPCX_PAIR_NS::kPairs;
+    int64_t b0 = (int64_t)blockIdx.x * MPCX_PAIR_NS::kPairs;
     // the wave's records [first, nb) are solved: all that exist, or those inside the caller's range
     int64_t r_lo = 0, r_hi = a.B;
-    if (RANGE) {
+    const mpcx_variant *vp = &a.v;
+    if (RANGE == 1) {
         r_lo = a.range[0] > 0 ? a.range[0] : 0;
         r_hi = a.range[1] < a.B ? a.range[1] : a.B;
         if (b0 + MPCX_PAIR_NS::kPairs <= r_lo || b0 >= r_hi) return;   // wave-uniform
     }
+    if (RANGE == 2) {
+        // which run this wavefront belongs to: run m owns the wavefronts that its instances touch
+        int w = blockIdx.x, m = 0;
+        bool mine = false;
+        for (; m < a.n_modes; ++m) {
+            r_lo = a.range[m] > 0 ? a.range[m] : 0;
+            r_hi = a.range[m + 1] < a.B ? a.range[m + 1] : a.B;
+            const int nw = r_hi > r_lo ? (int)((r_hi - 1) / MPCX_PAIR_NS::kPairs - r_lo / MPCX_PAIR_NS::kPairs) + 1 : 0;
+            if (w < nw) { mine = true; break; }
+            w -= nw;
+        }
+        if (!mine) return;   // wave-uniform
+        b0 = (r_lo / MPCX_PAIR_NS::kPairs + w) * MPCX_PAIR_NS::kPairs;
+        vp = a.vtab + m;
+    }
+    const mpcx_variant &v = *vp;
     const int nb = r_hi - b0 < MPCX_PAIR_NS::kPairs ? (int)(r_hi - b0) : MPCX_PAIR_NS::kPairs;
     const int first = r_lo > b0 ? (int)(r_lo - b0) : 0;
     const int pl = lane >> 1;

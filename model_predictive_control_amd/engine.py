@@ -375,8 +375,9 @@ class SegmentedLoop:
     A tick never waits for the device (no host round trip, every launch on the current stream):
     reference windows for the whole fleet; the vehicles sorted by the mode they are in (a stable
     device sort; vehicles at rest last) and their solve inputs gathered in that order; one solve
-    per mode over its run of the sorted batch, the run's bounds staying in device memory
-    (mpcx_solve_range_batch); controls and statuses scattered back; state advance and goal test;
+    launch for the whole sorted fleet, every mode's run with its own variant and the runs' bounds
+    staying in device memory (mpcx_solve_modes_batch); controls and statuses scattered back; state
+    advance and goal test;
     segment hand-over (mpcx_segment_step_batch) and the first nearest index of the vehicles that
     entered a segment.  That needs solves the T = 5 lane-pair kernel takes (every mpc_sim mode
     does); other variant sets fall back to one compacted launch per mode with the host reading
@@ -421,26 +422,38 @@ class SegmentedLoop:
         self._pind_next = torch.zeros(B, dtype=torch.int32, device=dev)
         self._enter = torch.zeros(B, dtype=torch.uint8, device=dev)
         self._ind_tmp = torch.zeros(B, dtype=torch.int32, device=dev)
-        self._mode_ids = torch.arange(M + 1, dtype=torch.int64, device=dev)
-        self._rest = torch.full((B,), M, dtype=torch.int64, device=dev)
-        self._streams = [torch.cuda.Stream(device=dev) for _ in range(M)]
-        self.device_resident = self._range_solve_available()
+        self._was_active = torch.zeros(B, dtype=torch.uint8, device=dev)
+        self._order = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._bounds = torch.zeros(M + 2, dtype=torch.int32, device=dev)
+        self._seg_mode32 = self.seg_mode.to(torch.int32)
+        self._gathered = dict(x0=torch.empty_like(self.x0), xref=torch.empty_like(self.xref), up=torch.empty_like(self.uprev),
+                              hp=torch.zeros(B, dtype=torch.uint8, device=dev))
+        n_scratch = self.lib.mpcx_mode_sort_scratch_ints(B, M)
+        self._scratch = torch.zeros(max(1, n_scratch), dtype=torch.int32, device=dev) if n_scratch >= 0 else None
+        self.device_resident = self._scratch is not None and self._range_solve_available()
         self._enter_segment(torch.nonzero(self.finished == 0).flatten())
         if self.log is not None:
             self.log[0].copy_(self.state)
 
     def _range_solve_available(self) -> bool:
-        """Whether every mode's solve can be given a device-resident range (an empty one here)."""
+        """Whether the modes' solves can go as one launch over the mode-sorted fleet (tried here with
+        empty runs).  Sets up the variant table the kernel reads: a host array and its device copy."""
+        M = len(self.variants)
+        self._vtab_host = (_lib.CVariant * M)(*self.variants)
+        raw = np.frombuffer(bytes(self._vtab_host), dtype=np.uint8).copy()
+        self._vtab_dev = torch.from_numpy(raw).to(self.state.device)
         o = self._sorted
-        empty = torch.zeros(2, dtype=torch.int32, device=self.state.device)
-        for v in self.variants:
-            rc = self.lib.mpcx_solve_range_batch(C.byref(v), self.B, _ptr(empty), _ptr(self.x0), _ptr(self.xref),
-                                                 _ptr(self.uprev), _ptr(self.has_prev), _ptr(o["u"]), _ptr(o["x"]),
-                                                 _ptr(o["obj"]), _ptr(o["status"]), _ptr(o["iters"]), _stream())
-            if rc == _lib.E_UNSUPPORTED:
-                return False
-            _lib.check(rc)
+        empty = torch.zeros(M + 1, dtype=torch.int32, device=self.state.device)
+        rc = self._solve_modes(empty, self.x0, self.xref, self.uprev, self.has_prev, o)
+        if rc == _lib.E_UNSUPPORTED:
+            return False
+        _lib.check(rc)
         return True
+
+    def _solve_modes(self, bounds, x0, xref, up, hp, o):
+        return self.lib.mpcx_solve_modes_batch(C.cast(self._vtab_host, C.c_void_p), len(self.variants), _ptr(self._vtab_dev),
+                                               _ptr(bounds), self.B, _ptr(x0), _ptr(xref), _ptr(up), _ptr(hp), _ptr(o["u"]),
+                                               _ptr(o["x"]), _ptr(o["obj"]), _ptr(o["status"]), _ptr(o["iters"]), _stream())
 
     def _enter_segment(self, idx):
         """What doSimulation does before its loop (mpc_sim.py:204-222) for the vehicles `idx`
@@ -486,31 +499,19 @@ class SegmentedLoop:
             return self._tick_with_host_lists()
         t, lib, st, M = self.table, self.lib, _stream(), len(self.variants)
         self._nearest(self.target_ind, self.target_ind, self.xref, self.x0)   # x0 = [state.x, state.y, state.yaw]
-        active = (self.finished == 0) & (self.done == 0)
-        was_active = active.to(torch.uint8)
-        mode = self.seg_mode[self.course_id.long().clamp(0, t.K - 1)]
-        key = torch.where(active, mode, self._rest)                       # vehicles at rest sort last
-        skey, order = torch.sort(key, stable=True)
-        bounds = torch.searchsorted(skey, self._mode_ids).to(torch.int32)  # run of mode m: bounds[m] .. bounds[m + 1]
-        g_x0, g_xref = self.x0.index_select(0, order), self.xref.index_select(0, order)
-        g_up, g_hp = self.uprev.index_select(0, order), self.has_prev.index_select(0, order)
-        so = self._sorted
-        # one launch per mode, each on a stream of its own: a mode's run fills only part of the chip,
-        # and the runs touch disjoint rows, so the launches may overlap; the main stream waits for all
-        main = torch.cuda.current_stream()
-        for m, v in enumerate(self.variants):
-            side = self._streams[m]
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                _lib.check(lib.mpcx_solve_range_batch(C.byref(v), self.B, C.c_void_p(bounds.data_ptr() + 4 * m), _ptr(g_x0),
-                                                      _ptr(g_xref), _ptr(g_up), _ptr(g_hp), _ptr(so["u"]), _ptr(so["x"]),
-                                                      _ptr(so["obj"]), _ptr(so["status"]), _ptr(so["iters"]), _stream()))
-        for side in self._streams:
-            main.wait_stream(side)
-        o = self.out
+        v0, so, o, g = self.variants[0], self._sorted, self.out, self._gathered
+        was_active = self._was_active
+        # the fleet sorted by mode (vehicles at rest last), the solve's inputs gathered in that order
+        _lib.check(lib.mpcx_mode_sort_batch(self.B, M, v0.nu, v0.T, _ptr(self.finished), _ptr(self.done), _ptr(self.course_id),
+                                            _ptr(self._seg_mode32), t.K, _ptr(self.x0), _ptr(self.xref), _ptr(self.uprev),
+                                            _ptr(self.has_prev), _ptr(was_active), _ptr(self._order), _ptr(self._bounds),
+                                            _ptr(g["x0"]), _ptr(g["xref"]), _ptr(g["up"]), _ptr(g["hp"]), _ptr(self._scratch), st))
+        # one launch for all modes: every run of the sorted fleet gets wavefronts of its own and its
+        # mode's variant (MPC.iterativeLMPC's dispatch on `mode`, mpc_sim.py:301-306)
+        _lib.check(self._solve_modes(self._bounds, g["x0"], g["xref"], g["up"], g["hp"], so))
         # rows past the last run (vehicles at rest) carry stale values; the advance ignores them (done != 0)
-        o["u"].index_copy_(0, order, so["u"])
-        o["status"].index_copy_(0, order, so["status"])
+        _lib.check(lib.mpcx_mode_unsort_batch(self.B, v0.nu, v0.T, _ptr(self._order), _ptr(so["u"]), _ptr(so["status"]),
+                                              _ptr(o["u"]), _ptr(o["status"]), st))
         k = self.n_done_ticks + 1
         self._advance(k)
         o["u"], self.uprev = self.uprev, o["u"]

@@ -86,7 +86,7 @@ st = kernel_stats("trace", "t", f"{rnd}_bench_kernel_stats.csv")
 t = traffic("pmc_fetch", "pmc_write", "k_solve_pair5")
 if t:
     t.update(kernel="k_solve_pair5", batch=65536, csrc_sha=sha, how=how + "; FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B)")
-    ns, calls = avg_ns(st, "k_solve_pair5<1, false, false>")
+    ns, calls = avg_ns(st, "k_solve_pair5<1, false, 0>")
     t["kernel_trace_avg_ns"] = ns
     json.dump(t, open(os.path.join(PROF, "hbm_traffic.json"), "w"), indent=1)
     print("headline traffic", t["bytes_per_launch"], "avg ns", ns)
@@ -112,7 +112,7 @@ st = kernel_stats("ch_trace", "p", f"{rnd}_chain_kernel_stats.csv")
 t = traffic("ch_fetch", "ch_write", "k_solve_pair5")
 pw = sq(["ch_sq_a", "ch_sq_b"], "k_solve_pair5")
 if t or pw:
-    ns, calls = avg_ns(st, "k_solve_pair5<1, true, false>")
+    ns, calls = avg_ns(st, "k_solve_pair5<1, true, 0>")
     rec = {"kernel": "k_solve_pair5<dual-steer, chain>", "variant": "sim_ackermann", "batch": 65536, "csrc_sha": sha, "avg_ns": ns,
            "launches": calls, "algorithmic_bytes": 65536 * 649, "traffic": t, "per_wave": pw,
            "valu_busy_frac": (pw.get("SQ_ACTIVE_INST_VALU", 0.0) / pw["SQ_WAVE_CYCLES"]) if pw and pw.get("SQ_WAVE_CYCLES") else None, "how": how}

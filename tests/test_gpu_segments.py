@@ -163,3 +163,49 @@ def test_device_resident_ticks_equal_the_host_list_ticks():
     a, b = loops
     for name in ("state", "ticks", "done", "finished", "seg", "target_ind", "course_id", "has_prev", "log"):
         np.testing.assert_array_equal(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy(), err_msg=name)
+
+
+@pytest.mark.parametrize("names", [("sim_ackermann", "sim_diff", "sim_crab"), ("dsr_ackermann", "dsr_crab", "dsr_diff")])
+def test_one_launch_over_the_sorted_fleet_equals_one_ranged_launch_per_mode(names):
+    """mpcx_solve_modes_batch (every run of the mode-sorted batch with its own variant, one launch)
+    against mpcx_solve_range_batch per mode: the same answers to 1e-12, for runs that begin and end in the
+    middle of a wavefront's 32 instances, an empty run, and rows past the last run left untouched."""
+    import ctypes as C
+    from model_predictive_control_amd import _lib, engine, variants
+    from tests.helpers import make_problem
+    lib = _lib.load()
+    B = 5000
+    vs = [variants.get(n) for n in names]
+    v, ov, x0, xref = make_problem(names[0], B, seed=61)
+    d_x0, d_xref = engine._dev(x0), engine._dev(xref)
+    cold = engine.solve_batch(vs[0], d_x0, d_xref)
+    up = cold["u"].clone()
+    hp = torch.from_numpy((np.arange(B) % 4 != 0).astype(np.uint8)).cuda()
+    host = (_lib.CVariant * 3)(*vs)
+    dev = torch.from_numpy(np.frombuffer(bytes(host), dtype=np.uint8).copy()).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for bounds in ([0, 1777, 3301, 4990], [13, 13, 2048, 4096], [0, 32, 64, 5000]):
+        d_b = torch.tensor(bounds, dtype=torch.int32, device="cuda")
+        one = engine._outputs(B, vs[0].nu, vs[0].T, d_x0.device)
+        per = engine._outputs(B, vs[0].nu, vs[0].T, d_x0.device)
+        for o in (one, per):
+            o["u"].fill_(-3.0); o["x"].fill_(-3.0); o["obj"].fill_(-3.0); o["status"].fill_(-3); o["iters"].fill_(-3)
+        _lib.check(lib.mpcx_solve_modes_batch(C.cast(host, C.c_void_p), 3, p(dev), p(d_b), B, p(d_x0), p(d_xref), p(up), p(hp),
+                                              p(one["u"]), p(one["x"]), p(one["obj"]), p(one["status"]), p(one["iters"]), None))
+        for m, vm in enumerate(vs):
+            _lib.check(lib.mpcx_solve_range_batch(C.byref(vm), B, C.c_void_p(d_b.data_ptr() + 4 * m), p(d_x0), p(d_xref), p(up),
+                                                  p(hp), p(per["u"]), p(per["x"]), p(per["obj"]), p(per["status"]), p(per["iters"]), None))
+        torch.cuda.synchronize()
+        # two instantiations of one kernel: the same arithmetic, scheduled (and contracted) apart
+        for k in ("status", "iters"):
+            assert torch.equal(one[k], per[k]), (bounds, k)
+        for k in ("u", "x", "obj"):
+            assert torch.allclose(one[k], per[k], rtol=1e-12, atol=1e-12, equal_nan=True), (bounds, k, float((one[k] - per[k]).abs().nan_to_num().max()))
+        st = one["status"].cpu().numpy()
+        # written inside the runs (a mode's variant on another mode's warm start may be infeasible), untouched outside
+        assert (st[bounds[0]:bounds[3]] >= 0).all() and (st[:bounds[0]] == -3).all() and (st[bounds[3]:] == -3).all()
+        assert (st[bounds[0]:bounds[1]] == 0).all()
+    # modes that cannot share a launch are refused
+    mixed = (_lib.CVariant * 2)(variants.get("sim_ackermann"), variants.get("dsr_ackermann"))
+    assert lib.mpcx_solve_modes_batch(C.cast(mixed, C.c_void_p), 2, p(dev), p(d_b), B, p(d_x0), p(d_xref), p(up), p(hp), p(one["u"]),
+                                      p(one["x"]), p(one["obj"]), p(one["status"]), p(one["iters"]), None) == _lib.E_ARG
