@@ -29,3 +29,6 @@ print("active-set rounds per wave: mean", st[:, 7].mean(), "hist", np.bincount(s
 print("waves taking the fallback:", int(fb.sum()), "of", n)
 for nm, d in ph.items():
     print(f"{nm:9s} median {np.median(d):9.0f} mean {d.mean():9.0f} cycles")
+tot = (st[:, 6] - st[:, 0]).astype(float)
+print("wavefront time, cycles: percentiles 1/50/90/99/100:", [int(np.percentile(tot, q)) for q in (1, 50, 90, 99, 100)],
+      "(a launch of 2,048 wavefronts on 1,024 SIMDs takes two of them back to back)")
