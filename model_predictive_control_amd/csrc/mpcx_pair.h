@@ -38,6 +38,15 @@ typedef MPCX_PAIR_AUX aux_t;             // storage type of the reciprocal slack
 #ifndef MPCX_PAIR_MU0
 #define MPCX_PAIR_MU0 0.05
 #endif
+#ifndef MPCX_PAIR_GUESS
+#define MPCX_PAIR_GUESS 0.15
+#endif
+// The first active set of the rounds: constraints whose multiplier exceeds kPairGuess x their slack at
+// the interior-point iterate.  Erring towards inclusion pays: measured on 65,536 instances of every
+// T = 5 variant, closed-loop and random inputs, warm starts take 3-9 % less with 0.15 than with 1 (the
+// general bicycle 79.6 -> 76.0 us; a numpy model of the kernel: 2.94 against 3.33 rounds for the
+// slowest of 32 instances), cold starts 2 % more, the 2^t-weighted fixed-steer mode 3 % more.
+constexpr double kPairGuess = MPCX_PAIR_GUESS;
 constexpr double kPairMu0 = MPCX_PAIR_MU0;   // initial complementarity s*lambda at gradients up to 1
 constexpr int TT = MPCX_PAIR_TT;         // horizon = number of 2x2 block rows
 constexpr int NBLK = TT * (TT + 1) / 2;  // lower-triangular blocks
@@ -510,14 +519,14 @@ __device__ __forceinline__ bool pdas(State &s, bool skip, int max_rounds, int *r
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
         const double wi = s.ws[t];
-        const bool au = s.lamU[t] > s.hi(t) - wi, al = s.lamL[t] > wi - s.lo(t);
+        const bool au = s.lamU[t] > kPairGuess * (s.hi(t) - wi), al = s.lamL[t] > kPairGuess * (wi - s.lo(t));
         s.isu[t] = au ? 1.0 : 0.0; s.isl[t] = al ? 1.0 : 0.0;
         s.lamU[t] = au ? s.lamU[t] : 0.0; s.lamL[t] = al ? s.lamL[t] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < NRT; ++i) {
         const double dv = s.ws[i + 1] - s.ws[i];
-        const bool au = s.nuU[i] > s.rr - dv, al = s.nuL[i] > s.rr + dv;
+        const bool au = s.nuU[i] > kPairGuess * (s.rr - dv), al = s.nuL[i] > kPairGuess * (s.rr + dv);
         s.iru[i] = au ? 1.0 : 0.0; s.irl[i] = al ? 1.0 : 0.0;
         s.nuU[i] = au ? s.nuU[i] : 0.0; s.nuL[i] = al ? s.nuL[i] : 0.0;
     }

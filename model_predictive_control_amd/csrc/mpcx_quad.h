@@ -399,6 +399,14 @@ __device__ __forceinline__ void ipm(State<TT> &s, int max_iter, bool fixed, bool
     iters = my_iters;
 }
 
+#ifndef MPCX_QUAD_GUESS
+#define MPCX_QUAD_GUESS 0.5
+#endif
+// first active set: multiplier > kQuadGuess x slack (see kPairGuess; mpc.py's controller, 32,768 / 65,536
+// warm instances: 218 / 418 us with 1, 211 / 408 us with 0.5; with 0.3 or 0.15 the larger batch takes 404 us
+// but one instance of the smaller one needs the second attempt, and its launch 275 us)
+constexpr double kQuadGuess = MPCX_QUAD_GUESS;
+
 // Primal-dual active-set rounds on the quad (mpcx_pair.h, pdas): one Newton step of the augmented
 // Lagrangian of the equality-constrained QP on the current set per round, first-order multiplier
 // update, set correction; a lane settles when its set stood still and the point passes the KKT
@@ -415,7 +423,7 @@ __device__ __forceinline__ bool pdas(State<TT> &s, bool skip, int max_rounds, in
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
         const double f = s.form(s.ws, t);
-        const bool au = s.is_used(t) && s.lamU[t] > s.bu(t) - f, al = s.is_used(t) && s.lamL[t] > f - s.bl(t);
+        const bool au = s.is_used(t) && s.lamU[t] > kQuadGuess * (s.bu(t) - f), al = s.is_used(t) && s.lamL[t] > kQuadGuess * (f - s.bl(t));
         s.isu[t] = au ? 1.0 : 0.0; s.isl[t] = al ? 1.0 : 0.0;
         s.lamU[t] = au ? s.lamU[t] : 0.0; s.lamL[t] = al ? s.lamL[t] : 0.0;
     }

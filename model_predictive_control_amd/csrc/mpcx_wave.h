@@ -439,6 +439,13 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool r
     }
 }
 
+#ifndef MPCX_WAVE_GUESS
+#define MPCX_WAVE_GUESS 1.0
+#endif
+// first active set: multiplier > kWaveGuess x slack (see kPairGuess; here 0.3 changes nothing and 0.15
+// costs the 2^t-weighted T = 30 variant 17 %: an instance has its wavefront to itself, nobody waits)
+constexpr double kWaveGuess = MPCX_WAVE_GUESS;
+
 // Primal-dual active-set rounds (see pdas() of the pair kernels).  Returns true when the
 // point is certified; otherwise the controls are put back as they were.
 template <int NFIX>
@@ -450,8 +457,8 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
     bool au, al, bu, bl;
     {
         const double dv = from_next(c.w, i) - c.w;
-        au = c.hb && c.lamU > c.hi - c.w; al = c.hb && c.lamL > c.w - c.lo;
-        bu = c.hr && c.nuU > c.rr - dv; bl = c.hr && c.nuL > c.rr + dv;
+        au = c.hb && c.lamU > kWaveGuess * (c.hi - c.w); al = c.hb && c.lamL > kWaveGuess * (c.w - c.lo);
+        bu = c.hr && c.nuU > kWaveGuess * (c.rr - dv); bl = c.hr && c.nuL > kWaveGuess * (c.rr + dv);
         c.lamU = au ? c.lamU : 0.0; c.lamL = al ? c.lamL : 0.0;
         c.nuU = bu ? c.nuU : 0.0; c.nuL = bl ? c.nuL : 0.0;
     }
