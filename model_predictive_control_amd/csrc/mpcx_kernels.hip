@@ -388,78 +388,89 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
         }
         const double rwc = ch ? rw[1] : rw[0], rdc = ch ? rdw[1] : rdw[0];
         if (NFIX > 0) {
-            // One horizon: lane i accumulates row i of H in registers (the entries of G of the
-            // other lanes arrive through v_readlane) and writes it to the packed triangle once.
-            // A stage updates all the columns of its half of the horizon: the lanes of later stages
-            // still hold G = 0, so the columns it does not reach receive zeros, and the stage loops
-            // stay rolled (unrolled, their LDS reads are hoisted and spill).  Slots right of the diagonal
-            // collect products that are never stored.
+            // One horizon: H = sum over stages and state components of (2 Q_r G_r)(G_r)' is a sum of
+            // rank-3 updates, which the matrix cores take as 16 x 16 tiles (v_mfma_f64_16x16x4, the
+            // fourth column of the operands zero): ten tiles cover the lower triangle of the 64 x 64
+            // frame, four doubles per lane each.  Per stage the lanes publish their three entries of G
+            // in LDS and read them back in operand order (lane l: entry of row 16 I + (l & 15), component
+            // l >> 4); tiles that only lanes of later stages reach are still zero and are skipped.
             constexpr int N = NFIX > 0 ? NFIX : 2, TF = N / 2;
-            double Hrow[N];
-            {
-                double d = 2.0 * rwc;
-                if (st_own > 0) d += 2.0 * rdc;
-                if (st_own + 1 < TF) d += 2.0 * rdc;
+            typedef double tile_t __attribute__((ext_vector_type(4)));
+            tile_t Ht[10];
 #pragma unroll
-                for (int k = 0; k < N; ++k) Hrow[k] = k == lane ? d : (k + 2 == lane ? -2.0 * rdc : 0.0);
-            }
+            for (int q = 0; q < 10; ++q) Ht[q] = tile_t{0.0, 0.0, 0.0, 0.0};
+            volatile wave::lds_double *gb = c.K;     // [4][64], K's area is idle until the first factorisation
+            const int kq = lane >> 4, m16 = lane & 15;
+            gb[3 * kWave + lane] = 0.0;
             double p[3] = {x0[0], x0[1], x0[2]}, G[3] = {0.0, 0.0, 0.0}, gacc = 0.0, qg = 1.0;
-            // stages t0 .. t1 - 1, which reach columns 0 .. KMAX - 1 at most
-            auto stages = [&](int t0, int t1, auto kmax) {
-                constexpr int KMAX = decltype(kmax)::value;
 #pragma unroll 1
-                for (int t = t0; t < t1; ++t) {
-                    volatile wave::lds_double *d = dyn + 11 * t;
-                    const double a02 = d[0], a12 = d[1];
-                    const double ct0 = d[8], ct1 = d[9], ct2 = d[10];
-                    const double pn0 = p[0] + a02 * p[2] + ct0;
-                    const double pn1 = p[1] + a12 * p[2] + ct1;
-                    const double pn2 = p[2] + ct2;
-                    p[0] = pn0; p[1] = pn1; p[2] = pn2;
-                    if (lane < 2 * t) {
-                        G[0] = fma(a02, G[2], G[0]);
-                        G[1] = fma(a12, G[2], G[1]);
-                    }
-                    if (c.act && st_own == t) {
+            for (int t = 0; t < TF; ++t) {
+                volatile wave::lds_double *d = dyn + 11 * t;
+                const double a02 = d[0], a12 = d[1];
+                const double ct0 = d[8], ct1 = d[9], ct2 = d[10];
+                const double pn0 = p[0] + a02 * p[2] + ct0;
+                const double pn1 = p[1] + a12 * p[2] + ct1;
+                const double pn2 = p[2] + ct2;
+                p[0] = pn0; p[1] = pn1; p[2] = pn2;
+                if (lane < 2 * t) {
+                    G[0] = fma(a02, G[2], G[0]);
+                    G[1] = fma(a12, G[2], G[1]);
+                }
+                if (c.act && st_own == t) {
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) G[r] = d[2 + 2 * r + ch];
-                    }
-                    const int ts = t + 1;
-                    double Qs[3];
-                    if (ts < TF) {
-                        qg *= v.q_growth;
+                    for (int r = 0; r < 3; ++r) G[r] = d[2 + 2 * r + ch];
+                }
+                const int ts = t + 1;
+                double Qs[3];
+                if (ts < TF) {
+                    qg *= v.q_growth;
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) Qs[r] = v.Q[r] * qg;
-                    } else {
+                    for (int r = 0; r < 3; ++r) Qs[r] = v.Q[r] * qg;
+                } else {
 #pragma unroll
-                        for (int r = 0; r < 3; ++r) Qs[r] = v.Qf[r];
-                    }
-                    double gi[3];
+                    for (int r = 0; r < 3; ++r) Qs[r] = v.Qf[r];
+                }
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        gi[r] = 2.0 * Qs[r] * G[r];
-                        gacc = fma(gi[r], p[r] - xr[r * W + ts], gacc);
-                    }
+                for (int r = 0; r < 3; ++r) {
+                    gacc = fma(2.0 * Qs[r] * G[r], p[r] - xr[r * W + ts], gacc);
+                    gb[r * kWave + lane] = G[r];
+                }
+                __builtin_amdgcn_wave_barrier();
+                const double qk = kq == 0 ? 2.0 * Qs[0] : kq == 1 ? 2.0 * Qs[1] : kq == 2 ? 2.0 * Qs[2] : 0.0;
+                double gt[4];
 #pragma unroll
-                    for (int k = 0; k < KMAX; ++k) {
-                        double h = Hrow[k];
-                        h = fma(gi[0], wave::bcast(G[0], k), h);
-                        h = fma(gi[1], wave::bcast(G[1], k), h);
-                        h = fma(gi[2], wave::bcast(G[2], k), h);
-                        Hrow[k] = h;
+                for (int I = 0; I < 4; ++I) gt[I] = gb[kq * kWave + 16 * I + m16];
+#pragma unroll
+                for (int I = 0; I < 4; ++I) {
+                    if (16 * I < 2 * ts) {
+                        const double ai = gt[I] * qk;
+#pragma unroll
+                        for (int J = 0; J <= I; ++J)
+                            Ht[I * (I + 1) / 2 + J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, gt[J], Ht[I * (I + 1) / 2 + J], 0, 0, 0);
                     }
                 }
-            };
-            constexpr int TH = TF / 2;   // the first half of the stages reaches half of the columns
-            stages(0, TH, std::integral_constant<int, 2 * TH>());
-            stages(TH, TF, std::integral_constant<int, N>());
-            {
-                int tk = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
+            // tile (I, J), register i of lane l = element (16 I + (l >> 4) + 4 i, 16 J + (l & 15))
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    if (lane >= k && c.act) c.H[tk + lane] = Hrow[k];
-                    tk += N - 1 - k;
+            for (int J = 0; J < 4; ++J) {
+                const int col = 16 * J + m16;
+                const int tc = c.tri(col < N ? col : 0);
+#pragma unroll
+                for (int I = J; I < 4; ++I) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = 16 * I + kq + 4 * i;
+                        if (row >= col && row < N) c.H[tc + row] = Ht[I * (I + 1) / 2 + J][i];
+                    }
                 }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (c.act) {
+                double dd = 2.0 * rwc;
+                if (st_own > 0) { dd += 2.0 * rdc; c.H[c.tri(lane - 2) + lane] -= 2.0 * rdc; }
+                if (st_own + 1 < TF) dd += 2.0 * rdc;
+                c.H[c.own + lane] += dd;
             }
             __builtin_amdgcn_wave_barrier();
             c.g = c.act ? gacc : 0.0;

@@ -23,27 +23,44 @@ namespace wave {
 
 typedef __attribute__((address_space(3))) double lds_double;
 
-__device__ __forceinline__ double wsum(double x)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-    return x;
-}
-__device__ __forceinline__ double wmax(double x)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x = dmax(x, __shfl_xor(x, off, kWave));
-    return x;
-}
 // value of lane j on every lane, j wave-uniform: two v_readlane, no trip through LDS
 __device__ __forceinline__ double bcast(double x, int j)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), j), hi = __builtin_amdgcn_readlane(__double2hiint(x), j);
     return __hiloint2double(hi, lo);
 }
-// value of lane `lane - 2` / `lane + 2` (0 where there is none)
-__device__ __forceinline__ double from_prev(double x, int lane) { const double y = __shfl_up(x, 2, kWave); return lane >= 2 ? y : 0.0; }
-__device__ __forceinline__ double from_next(double x, int lane) { const double y = __shfl_down(x, 2, kWave); return lane < kWave - 2 ? y : 0.0; }
+// Lane exchanges by DPP (a few cycles each; __shfl compiles to ds_bpermute, an LDS round trip per
+// 32 bits, and a reduction is a chain of six of them).
+template <int CTRL>
+__device__ __forceinline__ double dpp(double x)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kQuadSwap1 = 0xB1, kQuadSwap2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140, kWaveShr1 = 0x138, kWaveShl1 = 0x130;
+// Reductions over the wavefront: a butterfly inside every row of 16 lanes (partner lanes 1 and 2 apart,
+// then mirrored in the half row and in the row: every lane ends with its row's result), and the four
+// rows' results from lanes 0, 16, 32, 48.
+__device__ __forceinline__ double wsum(double x)
+{
+    x += dpp<kQuadSwap1>(x);
+    x += dpp<kQuadSwap2>(x);
+    x += dpp<kRowHalfMirror>(x);
+    x += dpp<kRowMirror>(x);
+    return (bcast(x, 0) + bcast(x, 16)) + (bcast(x, 32) + bcast(x, 48));
+}
+__device__ __forceinline__ double wmax(double x)
+{
+    x = dmax(x, dpp<kQuadSwap1>(x));
+    x = dmax(x, dpp<kQuadSwap2>(x));
+    x = dmax(x, dpp<kRowHalfMirror>(x));
+    x = dmax(x, dpp<kRowMirror>(x));
+    return dmax(dmax(bcast(x, 0), bcast(x, 16)), dmax(bcast(x, 32), bcast(x, 48)));
+}
+// value of lane `lane - 2` / `lane + 2` (0 where there is none): two shifts of the whole wavefront by one
+__device__ __forceinline__ double from_prev(double x, int) { return dpp<kWaveShr1>(dpp<kWaveShr1>(x)); }
+__device__ __forceinline__ double from_next(double x, int) { return dpp<kWaveShl1>(dpp<kWaveShl1>(x)); }
 
 struct Ctx {
     volatile lds_double *H;     // packed lower triangle of H (see tri())
@@ -113,6 +130,27 @@ __device__ __forceinline__ double matvec(const Ctx &c, double v)
     return acc0 + acc1;   // n is even
 }
 
+// The same product for a horizon known at compile time: the vector goes through LDS and comes back as
+// broadcast reads (uniform addresses), the column offsets are constants.  K is not copied: the
+// blocked factorisation reads H itself.
+template <int N>
+__device__ __forceinline__ double matvec_fixed(const Ctx &c, double v)
+{
+    c.vec[c.lane] = c.act ? v : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    double acc0 = c.g, acc1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; k += 2) {
+        const int t0 = (k * (2 * N - 1 - k)) >> 1, t1 = ((k + 1) * (2 * N - 2 - k)) >> 1;
+        const double h0 = c.H[k <= c.row ? t0 + c.row : c.own + k];
+        const double h1 = c.H[k + 1 <= c.row ? t1 + c.row : c.own + k + 1];
+        acc0 = fma(h0, c.vec[k], acc0);
+        acc1 = fma(h1, c.vec[k + 1], acc1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return acc0 + acc1;
+}
+
 // Q columns k .. k + Q - 1 of the trailing update K(i, c) -= le_i le_c + ld_i ld_c (c <= i):
 // the lane's own entries are read unconditionally (so the loads go out together; a lane
 // left of the diagonal reads a neighbouring column's entry and drops it), le_c / ld_c come
@@ -175,52 +213,171 @@ __device__ __forceinline__ void chol(const Ctx &c)
     }
 }
 
-// The same factorisation for a horizon known at compile time (N = 2T free controls): lane i takes
-// row i of the packed K into registers, the columns are eliminated one by one there (the column's
-// entry of lane k reaches the other lanes through v_readlane, N (N - 1) / 2 of them), and the factor
-// goes back to the packed triangle for the solves.  The version above walks the matrix in LDS and is
-// bound by the round trips (157 k cycles at N = 60, three quarters of the kernel's time; this one
-// 46 k; sending the column through LDS and reading it back as broadcasts instead: 78 k).
-// Entries right of the diagonal in a lane's registers are whatever the load found; they stay in
-// that lane (only entries at or below the diagonal are ever broadcast or stored).
+// The factorisation for a horizon known at compile time (N = 2T free controls, N <= 64, a multiple
+// of 4), blocked for the matrix cores.  The trailing matrix
+// lives in registers as ten 16 x 16 tiles of the lower triangle of a 64 x 64 frame (tile (I, J), register
+// i of lane l = element (16 I + (l >> 4) + 4 i, 16 J + (l & 15)): the accumulator layout of
+// v_mfma_f64_16x16x4); panels of four columns are eliminated one after the other:
+//   1. the lanes holding the panel's columns put them at their place in the packed triangle in LDS,
+//   2. lane r reads the four entries of row r back, and every lane the panel's 4 x 4 diagonal block
+//      (uniform addresses: broadcasts), factors the block and finishes its row: four columns of L,
+//      kept as the lane's row of the factor (forward substitution) and written to the triangle,
+//   3. the finished columns come back in operand order (lane l: row 16 I + (l & 15), column l >> 4 of
+//      the panel) and one MFMA per live tile applies the rank-4 update.
+// Against the column-by-column elimination in registers (one v_readlane pair per multiply-add, half of
+// them on entries right of the diagonal) the broadcasts are inside the matrix instruction; what is
+// left is the chain of 60 reciprocal square roots and three LDS round trips per panel.
+typedef double tile_t __attribute__((ext_vector_type(4)));
 template <int N>
-__device__ __forceinline__ void chol_regs(const Ctx &c, double (&R)[N])
+__device__ __forceinline__ void chol_mfma(const Ctx &c, double db, double dr, double (&R)[N], double (&C)[N])
 {
-    {
-        int tk = 0;
+    static_assert(N % 4 == 0 && N <= 64, "panels of four columns in a 64 x 64 frame");
+    const int kq = c.lane >> 4, m16 = c.lane & 15;
+    int tcol[4];       // tri() of the column this lane holds in the tiles of tile column J
 #pragma unroll
-        for (int k = 0; k < N; ++k) { R[k] = c.K[tk + c.row]; tk += N - 1 - k; }
-    }
+    for (int J = 0; J < 4; ++J) tcol[J] = c.tri(16 * J + m16 < N ? 16 * J + m16 : 0);
+    // K = H + the barrier (or penalty) terms: `db + dr + dr of lane - 2` on the diagonal, `-dr of
+    // lane - 2` two below it (same channel, previous stage); the lanes publish both, the tile
+    // registers that hold such an entry pick theirs up
+    const double dprev = from_prev(dr, c.lane);
+    c.vec[c.lane] = db + dr + dprev;
+    c.K[c.lane] = dprev;                       // K's area is free until the first panel comes in
+    __builtin_amdgcn_wave_barrier();
+    tile_t Kt[10];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const double r = rsqrt_nr(bcast(R[j], j));
-        const double lj = R[j] * r;              // lanes below the diagonal: L(i, j)
-        R[j] = c.lane == j ? r : lj;             // the diagonal slot keeps 1 / L_jj
+    for (int J = 0; J < 4; ++J)
 #pragma unroll
-        for (int k = j + 1; k < N; ++k) R[k] = fma(-lj, bcast(lj, k), R[k]);
-    }
-    {
-        int tk = 0;
+        for (int I = J; I < 4; ++I)
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            if (c.lane >= k && c.act) c.K[tk + c.lane] = R[k];
-            tk += N - 1 - k;
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * I + kq + 4 * i, col = 16 * J + m16;
+                const bool in = (I > J || row >= col) && 16 * I + 4 * i < N;
+                const double x = c.H[in ? tcol[J] + row : 0];
+                Kt[I * (I + 1) / 2 + J][i] = in ? x : 0.0;
+            }
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+        const int col = 16 * J + m16;
+        const double dd = c.vec[col], ds = c.K[col + 2 < kWave ? col + 2 : 0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (kq + 4 * i == m16) Kt[J * (J + 1) / 2 + J][i] += dd;
+            if (kq + 4 * i == m16 + 2) Kt[J * (J + 1) / 2 + J][i] -= ds;
         }
+        if (J < 3 && kq == m16 - 14) Kt[(J + 1) * (J + 2) / 2 + J][0] -= ds;
     }
     __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < N / 4; ++p) {
+        const int c0 = 4 * p, J = p >> 2, pc = p & 3;
+        // 1. the panel's columns, from the lanes that hold them
+        // (rows below N: 16 I + 4 i < N, N being a multiple of 4; at or below the diagonal: always in
+        // the tiles under the diagonal one, and there for registers i > pc, never for i < pc, and for
+        // i == pc where l >> 4 >= the column's place in the panel -- all but one test fold away)
+        if ((m16 >> 2) == pc) {
+#pragma unroll
+            for (int I = J; I < 4; ++I)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (16 * I + 4 * i >= N || (I == J && i < pc)) continue;
+                    const int row = 16 * I + kq + 4 * i;
+                    if (I > J || i > pc || kq >= (m16 & 3)) c.K[tcol[J] + row] = Kt[I * (I + 1) / 2 + J][i];
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // 2. rows and the diagonal block
+        int tq[4];
+        tq[0] = c.tri(c0);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) tq[q] = tq[q - 1] + N - 1 - (c0 + q - 1);
+        double a[4], d[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = c.K[tq[q] + c.row];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = q; r < 4; ++r) d[r][q] = c.K[tq[q] + c0 + r];
+        const double r0 = rsqrt_nr(d[0][0]);
+        const double l10 = d[1][0] * r0, l20 = d[2][0] * r0, l30 = d[3][0] * r0;
+        const double r1 = rsqrt_nr(fma(-l10, l10, d[1][1]));
+        const double l21 = fma(-l20, l10, d[2][1]) * r1, l31 = fma(-l30, l10, d[3][1]) * r1;
+        const double r2 = rsqrt_nr(fma(-l21, l21, fma(-l20, l20, d[2][2])));
+        const double l32 = fma(-l31, l21, fma(-l30, l20, d[3][2])) * r2;
+        const double r3 = rsqrt_nr(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d[3][3]))));
+        const double x0 = a[0] * r0;
+        const double x1 = fma(-x0, l10, a[1]) * r1;
+        const double x2 = fma(-x1, l21, fma(-x0, l20, a[2])) * r2;
+        const double x3 = fma(-x2, l32, fma(-x1, l31, fma(-x0, l30, a[3]))) * r3;
+        R[c0] = c.lane == c0 ? r0 : x0;
+        R[c0 + 1] = c.lane == c0 + 1 ? r1 : x1;
+        R[c0 + 2] = c.lane == c0 + 2 ? r2 : x2;
+        R[c0 + 3] = c.lane == c0 + 3 ? r3 : x3;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c.lane >= c0 + q && c.act) c.K[tq[q] + c.lane] = R[c0 + q];
+        __builtin_amdgcn_wave_barrier();
+        // 3. rank-4 update of the tiles that still hold live entries (rows and columns >= c0 + 4)
+        if (c0 + 4 < N) {
+            const int I0 = (c0 + 4) >> 4;
+            const int tk = kq == 0 ? tq[0] : kq == 1 ? tq[1] : kq == 2 ? tq[2] : tq[3];
+            double op[4];
+#pragma unroll
+            for (int I = I0; I < 4; ++I) {
+                const int row = 16 * I + m16;
+                const double x = c.K[tk + (row < N ? row : N - 1)];
+                op[I] = row < N ? x : 0.0;
+            }
+#pragma unroll
+            for (int Jc = I0; Jc < 4; ++Jc)
+#pragma unroll
+                for (int I = Jc; I < 4; ++I)
+                    Kt[I * (I + 1) / 2 + Jc] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[I], op[Jc], Kt[I * (I + 1) / 2 + Jc], 0, 0, 0);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // the factor comes back transposed: the lane's own column (entries above the diagonal are whatever
+    // the triangle's neighbouring column holds; the backward substitution never uses them)
+#pragma unroll
+    for (int j = 0; j < N; ++j) C[j] = c.K[c.own + j];
 }
 
 // NFIX: the number of free controls when the kernel is built for one horizon (0: any).  The
 // factor's rows then stay in registers for the forward substitutions that follow.
 template <int NFIX>
 struct Factor {
-    double R[NFIX > 0 ? NFIX : 1];
+    double R[NFIX > 0 ? NFIX : 1];   // lane i: row i of L (slot i: 1 / L_ii)
+    double C[NFIX > 0 ? NFIX : 1];   // lane i: column i of L (slot i: 1 / L_ii)
 };
-template <int NFIX>
-__device__ __forceinline__ void factor(const Ctx &c, Factor<NFIX> &F)
+// K diagonal and same-channel sub-diagonal terms: `db` on the lane's own diagonal entry, `dr`
+// for its rate constraint (touches (i, i), (i + 2, i + 2) and (i + 2, i)).
+__device__ __forceinline__ void add_terms(const Ctx &c, double db, double dr)
 {
-    if constexpr (NFIX > 0) chol_regs<NFIX>(c, F.R);
-    else chol(c);
+    const int i = c.lane;
+    const double dprev = from_prev(dr, i);
+    if (c.act) {
+        c.K[c.own + i] += db + dr + dprev;
+        if (i >= 2) c.K[c.tri(i - 2) + i] -= dprev;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// H w + g, and K = H + terms factored (see add_terms for db, dr)
+template <int NFIX>
+__device__ __forceinline__ double gradient(const Ctx &c, double v)
+{
+    if constexpr (NFIX > 0) return matvec_fixed<NFIX>(c, v);
+    else return matvec<true>(c, v);
+}
+template <int NFIX>
+__device__ __forceinline__ void factor(const Ctx &c, Factor<NFIX> &F, double db, double dr)
+{
+    if constexpr (NFIX > 0) {
+        chol_mfma<NFIX>(c, db, dr, F.R, F.C);
+    } else {
+        add_terms(c, db, dr);
+        chol(c);
+    }
 }
 
 // x <- K^-1 r with the factor left by chol(); every lane passes its entry and gets its entry.
@@ -298,36 +455,55 @@ __device__ __forceinline__ double solve_backward(const Ctx &c, double acc)
     return acc;
 }
 
-// x <- K^-1 r.  With the factor's rows in registers the forward substitution needs no LDS: lane j
-// scales its entry by 1 / L_jj (its diagonal slot), one v_readlane pair hands it to the lanes below.
-// The backward substitution walks columns, which only the packed triangle in LDS offers.
+// x <- K^-1 r.  With the factor's rows and columns in registers neither substitution touches LDS,
+// and both go four columns at a time: the four lanes of a block (a DPP quad, N being a multiple of 4)
+// substitute among themselves with quad broadcasts, then the block's four results go to the
+// remaining lanes through v_readlane and are applied there at once.  (Column by column the chain is a
+// multiply, a v_readlane pair and a multiply-add per column, each waiting for the one before.)
 template <int NFIX>
 __device__ __forceinline__ double solve(const Ctx &c, const Factor<NFIX> &F, double r)
 {
     double acc = c.act ? r : 0.0;
     if constexpr (NFIX > 0) {
+        const int q = c.lane & 3, blk = c.lane >> 2;
+        // forward: L y = r
 #pragma unroll
-        for (int j = 0; j < NFIX; ++j) {
-            const double yj = bcast(acc * F.R[j], j);
-            acc = c.lane == j ? yj : (c.lane > j && c.act ? fma(-F.R[j], yj, acc) : acc);
+        for (int p = 0; p < NFIX / 4; ++p) {
+            const int c0 = 4 * p;
+            double t = acc;
+            const double y0 = dpp<0x00>(t * F.R[c0]);
+            t = fma(-F.R[c0], y0, t);
+            const double y1 = dpp<0x55>(t * F.R[c0 + 1]);
+            t = fma(-F.R[c0 + 1], y1, t);
+            const double y2 = dpp<0xAA>(t * F.R[c0 + 2]);
+            t = fma(-F.R[c0 + 2], y2, t);
+            const double y3 = dpp<0xFF>(t * F.R[c0 + 3]);
+            const double own = q == 0 ? y0 : q == 1 ? y1 : q == 2 ? y2 : y3;
+            const double b0 = bcast(y0, c0), b1 = bcast(y1, c0), b2 = bcast(y2, c0), b3 = bcast(y3, c0);
+            const double below = fma(-F.R[c0 + 1], b1, fma(-F.R[c0], b0, acc)) - fma(F.R[c0 + 3], b3, F.R[c0 + 2] * b2);
+            acc = blk == p ? own : (blk > p ? below : acc);
         }
+        // backward: L' z = y
+#pragma unroll
+        for (int p = NFIX / 4 - 1; p >= 0; --p) {
+            const int c0 = 4 * p;
+            double t = acc;
+            const double z3 = dpp<0xFF>(t * F.C[c0 + 3]);
+            t = fma(-F.C[c0 + 3], z3, t);
+            const double z2 = dpp<0xAA>(t * F.C[c0 + 2]);
+            t = fma(-F.C[c0 + 2], z2, t);
+            const double z1 = dpp<0x55>(t * F.C[c0 + 1]);
+            t = fma(-F.C[c0 + 1], z1, t);
+            const double z0 = dpp<0x00>(t * F.C[c0]);
+            const double own = q == 0 ? z0 : q == 1 ? z1 : q == 2 ? z2 : z3;
+            const double b0 = bcast(z0, c0), b1 = bcast(z1, c0), b2 = bcast(z2, c0), b3 = bcast(z3, c0);
+            const double above = fma(-F.C[c0 + 1], b1, fma(-F.C[c0], b0, acc)) - fma(F.C[c0 + 3], b3, F.C[c0 + 2] * b2);
+            acc = blk == p ? own : (blk < p ? above : acc);
+        }
+        return c.act ? acc : 0.0;   // lanes beyond N ran along on whatever their registers held
     } else {
-        acc = solve_forward(c, acc);
+        return solve_backward(c, solve_forward(c, acc));
     }
-    return solve_backward(c, acc);
-}
-
-// K diagonal and same-channel sub-diagonal terms: `db` on the lane's own diagonal entry, `dr`
-// for its rate constraint (touches (i, i), (i + 2, i + 2) and (i + 2, i)).
-__device__ __forceinline__ void add_terms(const Ctx &c, double db, double dr)
-{
-    const int i = c.lane;
-    const double dprev = from_prev(dr, i);
-    if (c.act) {
-        c.K[c.own + i] += db + dr + dprev;
-        if (i >= 2) c.K[c.tri(i - 2) + i] -= dprev;
-    }
-    __builtin_amdgcn_wave_barrier();
 }
 
 // C' applied to per-constraint values: box part `tb` (upper minus lower) and rate part `tr`.
@@ -372,7 +548,9 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool r
     iters = 0;
     Factor<NFIX> F;
     for (int it = 0;; ++it) {
-        const double hw = matvec<true>(c, c.w);
+        MPCX_STAMP(11);
+        const double hw = gradient<NFIX>(c, c.w);
+        MPCX_STAMP(12);
         // slacks, barrier terms
         const double wn = from_next(c.w, i);
         const double su = dmax(c.hi - c.w, kSlackMin), sl = dmax(c.w - c.lo, kSlackMin);
@@ -380,7 +558,6 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool r
         const double ru = dmax(c.rr - dv, kSlackMin), rl = dmax(c.rr + dv, kSlackMin);
         const double isu = c.hb ? rcp_raw(su) : 0.0, isl = c.hb ? rcp_raw(sl) : 0.0;
         const double iru = c.hr ? rcp_raw(ru) : 0.0, irl = c.hr ? rcp_raw(rl) : 0.0;
-        add_terms(c, fma(c.lamU, isu, c.lamL * isl), fma(c.nuU, iru, c.nuL * irl));
         const double ctl = ct_apply(c, c.lamU - c.lamL, c.nuU - c.nuL);
         double musum = 0.0;
         if (c.hb) musum = fma(su, c.lamU, sl * c.lamL);
@@ -397,9 +574,12 @@ __device__ __forceinline__ void ipm(Ctx &c, int max_iter, double mu_stop, bool r
             status = (rdmax <= kLooseD * scale && mu <= kLooseMu) ? MPCX_ST_INACCURATE : MPCX_ST_FAILED;
             return;
         }
-        factor<NFIX>(c, F);
+        MPCX_STAMP(13);
+        factor<NFIX>(c, F, fma(c.lamU, isu, c.lamL * isl), fma(c.nuU, iru, c.nuL * irl));
+        MPCX_STAMP(14);
         // predictor
         const double dwa = solve<NFIX>(c, F, -hw);
+        MPCX_STAMP(15);
         const double dva = from_next(dwa, i) - dwa;
         const double xu = dwa * isu, xl = -dwa * isl, yu = dva * iru, yl = -dva * irl;
         double rp = 0.0, rdm = 1.0;
@@ -465,7 +645,7 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
     bool changed = true, accepted = false, eased = false;
     Factor<NFIX> F;
     for (int round = 0;; ++round) {
-        const double hw = matvec<true>(c, c.w);
+        const double hw = gradient<NFIX>(c, c.w);
         const double dv = from_next(c.w, i) - c.w;
         const double vu = c.w - c.hi, vl = c.lo - c.w, ru = dv - c.rr, rl = -dv - c.rr;
         const double cu = au ? vu : 0.0, cl = al ? vl : 0.0, du = bu ? ru : 0.0, dl = bl ? rl : 0.0;
@@ -475,7 +655,6 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
         double neg = dmax(dmax(-c.lamU, -c.lamL), dmax(-c.nuU, -c.nuL));
         if (c.hb) viol = dmax(vu, vl);
         if (c.hr) viol = dmax(viol, dmax(ru, rl));
-        add_terms(c, rho * ((au ? 1.0 : 0.0) + (al ? 1.0 : 0.0)), rho * ((bu ? 1.0 : 0.0) + (bl ? 1.0 : 0.0)));
         const double stat = wmax(c.act ? fabs(gl) : 0.0);
         const double scale = dmax(1.0, wmax(c.act ? dmax(fabs(c.g), fabs(hw - c.g)) : 0.0)) + 1.0;
         viol = wmax(viol); cact = wmax(cact); neg = wmax(neg);
@@ -497,7 +676,7 @@ __device__ __forceinline__ bool pdas(Ctx &c, int max_rounds, double hmax)
         }
         if (round >= max_rounds || !fin) break;
         MPCX_STAMP(8);
-        factor<NFIX>(c, F);
+        factor<NFIX>(c, F, rho * ((au ? 1.0 : 0.0) + (al ? 1.0 : 0.0)), rho * ((bu ? 1.0 : 0.0) + (bl ? 1.0 : 0.0)));
         MPCX_STAMP(9);
         const double step = solve<NFIX>(c, F, -(gl + ga));
         MPCX_STAMP(10);
