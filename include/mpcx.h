@@ -91,7 +91,7 @@ int mpcx_variant_by_name(const char *name, mpcx_variant *out);
  * T = 10 at every batch size), otherwise the per-lane arrays of the stage-wise kernel for one
  * launch (440 T bytes per instance, at most 262,144 instances per launch).  Small batches at other
  * horizons up to T = 32 are solved by a kernel that needs none, but are followed by a stage-wise
- * pass that solves again whatever that kernel reports as MPCX_ST_INACCURATE (rare; the pass
+ * pass that solves again whatever that kernel reports as MPCX_ST_INACCURATE or MPCX_ST_FAILED (rare; the pass
  * returns at once otherwise, and is left out when uprev and u_out are the same buffer, since it
  * starts from the same inputs), so they count as needing the workspace too.  The library keeps one grow-only buffer per device for
  * it; calls that need it are serialised per device (each waits on the device for the

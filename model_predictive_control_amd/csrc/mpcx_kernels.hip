@@ -645,8 +645,8 @@ __device__ const int kStageRounds[kStageAttempts] = {MPCX_STAGE_R0, 6, 6};
 #define MPCX_STAGE_OCC 1   // wavefronts per SIMD the register budget is set for
 #endif
 // REDO: a second pass over a batch that another solve kernel has already answered: only the
-// instances that kernel left MPCX_ST_INACCURATE are solved again (from the same inputs) and
-// rewritten; a wavefront without one returns at once.
+// instances that kernel left MPCX_ST_INACCURATE or MPCX_ST_FAILED are solved again (from the same
+// inputs) and rewritten; a wavefront without one returns at once.
 template <int MODEL, bool REDO = false>
 __global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs a, double *ws)
 {
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(kWave, MPCX_STAGE_OCC) void k_solve_stage(SolveArgs
     bool live = b < a.B;
     if (!live) b = a.B - 1;
     if (REDO) {
-        live = live && a.status_out[b] == MPCX_ST_INACCURATE;
+        live = live && (a.status_out[b] == MPCX_ST_INACCURATE || a.status_out[b] == MPCX_ST_FAILED);
         if (!__any(live)) return;
     }
     const int T = v.T, W = T + 1;
