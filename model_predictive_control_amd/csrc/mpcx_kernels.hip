@@ -1534,13 +1534,13 @@ static int64_t stage_chunk(int64_t B)
 // (256 CUs, per CU as many wavefronts as LDS and registers allow, in whole wavefronts per SIMD: a
 // fifth wavefront on a CU shares a SIMD with another and doubles the launch's time); one such round
 // takes less than the latency of a single stage-wise wavefront (measured, warm: T = 12, 3,072: 0.36 ms
-// against 0.54 ms), a second round does not.  At T = 30, where the instantiation with the Cholesky
-// in registers runs (one wavefront per SIMD, 1,024 instances in 0.50 ms), three rounds still do:
-// 3,072 instances warm 1.33 ms against 1.48 ms stage-wise (mpc_dsr.py's Q 2^t variant 2.8 against
-// 5.2 ms), 4,096 1.77 against 1.52 ms.
+// against 0.54 ms), a second round does not.  At T = 30, where the instantiation with the matrix
+// instructions runs (one wavefront per SIMD, 1,024 instances in 0.21 ms), eight rounds still do:
+// 8,192 instances warm 1.40 ms against 1.54 ms stage-wise (mpc_dsr.py's Q 2^t variant 2.6 against
+// 4.1 ms), 12,288 2.08 against 1.56 ms (scripts/wave_crossover.py).
 static int64_t wave_batch_max(int T)
 {
-    if (T == 30) return 3 * 1024;
+    if (T == 30) return 8 * 1024;
     const int64_t by_lds = (160 * 1024) / ((int64_t)wave_lds_doubles(T) * (int64_t)sizeof(double));
     const int64_t by_regs = 12;   // 3 wavefronts per SIMD at the kernel's register count
     int64_t per_cu = by_lds < by_regs ? by_lds : by_regs;
@@ -1616,6 +1616,19 @@ static int launch_stage_chunks(const SolveArgs &a, hipStream_t st, double *ws, i
 // with that device current, and kept.
 constexpr size_t kScratchBytes = (size_t)64 << 20;
 static __device__ __align__(256) double scratch[kScratchBytes / sizeof(double)];
+
+// 0 when the stage-wise kernel's arrays for B instances fit the fixed array of the entry point that
+// allocates nothing, otherwise the error it returns.
+static int fits_fixed_workspace(int64_t B, int T)
+{
+    const int64_t slots = ((B + kWave - 1) / kWave) * kWave;
+    const size_t per = (size_t)stage_doubles_per_instance(T) * sizeof(double);
+    const size_t need = per * (size_t)slots;
+    if (need <= kScratchBytes) return 0;
+    return fail(MPCX_E_NOMEM, "%lld instances at T=%d need %zu bytes of workspace; the entry point that "
+                "allocates nothing holds %zu (at most %lld instances at this horizon)", (long long)B, T,
+                need, kScratchBytes, (long long)(kScratchBytes / per / kWave * kWave));
+}
 static double *g_scratch_ptr[64] = {nullptr};
 static std::mutex g_scratch_mutex;
 
@@ -1709,6 +1722,10 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
         return 0;
     }
     case kPathWave: {
+        const bool second_pass = !(g_stagewise == 0 || (a.uin && (const void *)a.uin == (const void *)a.u_out));
+        // the caller that may not allocate is refused before anything is launched
+        if (second_pass && fixed_workspace)
+            if (int rc = fits_fixed_workspace(a.B, v->T)) return rc;
         // K and H of the instance in LDS
         const size_t lds = (size_t)wave_lds_doubles(v->T) * sizeof(double);
         const dim3 wgrid((unsigned)a.B);
@@ -1727,7 +1744,7 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
         // solves those again from the same inputs, which it can only do while the incoming
         // controls have not been overwritten by the answer.  A wavefront of that pass that finds
         // nothing to do returns at once.  Forcing this kernel through the test hook shows it raw.
-        if (g_stagewise == 0 || (a.uin && (const void *)a.uin == (const void *)a.u_out)) return 0;
+        if (!second_pass) return 0;
         redo = true;
         break;
     }
@@ -1742,12 +1759,7 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
     if (fixed_workspace) {
         // the caller may not allocate: the library's own fixed array, one launch, no event
         const int64_t slots = ((a.B + kWave - 1) / kWave) * kWave;
-        const size_t need = (size_t)stage_doubles_per_instance(v->T) * (size_t)slots * sizeof(double);
-        if (need > kScratchBytes)
-            return fail(MPCX_E_NOMEM, "%lld instances at T=%d need %zu bytes of workspace; the entry point that "
-                        "allocates nothing holds %zu (at most %lld instances at this horizon)", (long long)a.B, v->T,
-                        need, kScratchBytes,
-                        (long long)(kScratchBytes / ((size_t)stage_doubles_per_instance(v->T) * sizeof(double)) / kWave * kWave));
+        if (int rc = fits_fixed_workspace(a.B, v->T)) return rc;
         double *ws = nullptr;
         if (int rc = scratch_of_device(dev, &ws)) return rc;
         return launch_stage_chunks(a, st, ws, slots, redo);
