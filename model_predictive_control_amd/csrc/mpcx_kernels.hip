@@ -285,7 +285,8 @@ __host__ __device__ inline int wave_lds_doubles(int T)
     return n * (n + 1) + kWave + 11 * T + (T + 1);   // H and K (packed triangles), broadcast buffer, dynamics, yaw
 }
 
-// NFIX: 2T when the kernel is built for one horizon (its Cholesky then runs in registers), 0: any.
+// NFIX: 2T when the kernel is built for one horizon (condensing and Cholesky then run on the matrix
+// cores, the factor stays in registers), 0: any.
 template <int MODEL, int NFIX = 0>
 __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
 {
@@ -1729,7 +1730,7 @@ static int launch_solve(const SolveArgs &a, hipStream_t st, bool fixed_workspace
         // K and H of the instance in LDS
         const size_t lds = (size_t)wave_lds_doubles(v->T) * sizeof(double);
         const dim3 wgrid((unsigned)a.B);
-        if (v->T == 30) {   // mpc_dsr.py's long horizon: the instantiation with the Cholesky in registers
+        if (v->T == 30) {   // mpc_dsr.py's long horizon: the instantiation on the matrix cores
             if (m == 0) hipLaunchKernelGGL((k_solve_wave<0, 60>), wgrid, block, lds, st, a);
             else hipLaunchKernelGGL((k_solve_wave<1, 60>), wgrid, block, lds, st, a);
         } else {

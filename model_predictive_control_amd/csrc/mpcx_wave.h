@@ -9,6 +9,12 @@
 // them fit in under 30 KB at n = 60 and five instances share a compute unit: the kernel issues
 // one instruction stream per instance, and what it needs most is enough of them per SIMD.
 //
+// Built for one horizon (NFIX = 2T, used for the reference's T = 30) the kernel keeps only H in
+// LDS: K = H + barrier terms is formed and factorised in registers as 16 x 16 tiles of the f64
+// matrix instruction (chol_mfma), the factor stays in registers as rows and as columns for the two
+// substitutions (solve), H w is an unrolled walk with the vector broadcast from LDS (matvec_fixed).
+// That instantiation holds one wavefront per SIMD (the whole register file).
+//
 // Solver = the scheme of the stage-wise kernel on the condensed problem: interior-point
 // iterations (predictor-corrector, centring from the predictor's step lengths) until the
 // complementarity is small enough to read the active set off the iterate, then primal-dual
@@ -343,7 +349,7 @@ __device__ __forceinline__ void chol_mfma(const Ctx &c, double db, double dr, do
 }
 
 // NFIX: the number of free controls when the kernel is built for one horizon (0: any).  The
-// factor's rows then stay in registers for the forward substitutions that follow.
+// factor's rows and columns then stay in registers for the substitutions that follow.
 template <int NFIX>
 struct Factor {
     double R[NFIX > 0 ? NFIX : 1];   // lane i: row i of L (slot i: 1 / L_ii)
