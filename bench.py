@@ -199,6 +199,7 @@ def other_configs(steps: int = 3):
                                ("dsr_ackermann", 65536, 30, "k_solve_stage<dual-steer>"),
                                ("dsr_diff", 1024, 30, "k_solve_wave<dual-steer, T=30> (one wavefront per instance) + k_solve_stage<REDO>"),
                                ("dsr_ackermann", 1024, 30, "k_solve_wave<dual-steer, T=30> (one wavefront per instance) + k_solve_stage<REDO>"),
+                               ("dsr_ackermann", 8192, 30, "k_solve_wave<dual-steer, T=30> (the largest batch routed to it) + k_solve_stage<REDO>"),
                                ("dsr_diff", 1, 30, "k_solve_wave<dual-steer, T=30> (one wavefront per instance) + k_solve_stage<REDO>")):
         v = variants.get(name, T=T) if T else variants.get(name)
         inst = workload.make_instances(courses, B, seed=2003)
@@ -211,7 +212,7 @@ def other_configs(steps: int = 3):
         for start, u in (("cold", None), ("warm", up)):
             if start == "cold" and T != 30:
                 continue
-            n = steps if v.T > 10 and B > 4096 else 40 * steps      # the short kernels need more launches for a stable figure
+            n = steps if v.T > 10 and B > 16384 else (4 * steps if v.T > 10 and B > 4096 else 40 * steps)      # the short kernels need more launches for a stable figure
             for _ in range(max(1, n // 4)):
                 engine.solve_batch(v, d_x0, d_xref, u, out=out)
             torch.cuda.synchronize()
