@@ -282,7 +282,7 @@ __device__ const int kWaveRounds[kWaveAttempts] = {5, 5, 5};
 __host__ __device__ inline int wave_lds_doubles(int T)
 {
     const int n = 2 * T;
-    return n * (n + 1) + kWave + 11 * T + (T + 1);   // H and K (packed triangles), broadcast buffer, dynamics, yaw
+    return n * (n + 1) + kWave + 11 * T + (T + 1) + 3 * (T + 1);   // H and K (packed triangles), broadcast buffer, dynamics, yaw, reference window
 }
 
 // NFIX: 2T when the kernel is built for one horizon (condensing and Cholesky then run on the matrix
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
     c.H = (volatile wave::lds_double *)smem;
     c.K = c.H + c.size();
     c.vec = c.K + c.size();
-    volatile wave::lds_double *dyn = c.vec + kWave, *th = dyn + 11 * T;
+    volatile wave::lds_double *dyn = c.vec + kWave, *th = dyn + 11 * T, *xw = th + W;
     c.lane = lane; c.act = lane < n; c.row = c.act ? lane : 0; c.own = c.tri(c.row);
     MPCX_STAMP_CLEAR();
     MPCX_STAMP(0);
@@ -313,7 +313,11 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
     const bool warm = a.linear_mode || (uin && (!a.has_prev || a.has_prev[b]));
     // inputs: every lane checks a slice, the wave votes
     bool fin = finite_d(x0[0]) && finite_d(x0[1]) && finite_d(x0[2]);
-    for (int i = lane; i < 3 * W; i += kWave) fin = fin && finite_d(xr[i]);
+    for (int i = lane; i < 3 * W; i += kWave) {   // the window stays in LDS: the stage loops below read it
+        const double xv = xr[i];
+        fin = fin && finite_d(xv);
+        xw[i] = xv;
+    }
     if (a.linear_mode)
         for (int i = lane; i < 3 * W; i += kWave) fin = fin && finite_d(a.xbar[b * 3 * W + i]);
     double u[4] = {0.0, 0.0, 0.0, 0.0}, u0[4] = {0.0, 0.0, 0.0, 0.0};
@@ -337,12 +341,14 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
     if (a.linear_mode) {
         if (c.act && ch == 0) th[st_own] = a.xbar[b * 3 * W + 2 * W + st_own];
     } else {
-        if (c.act && ch == 0) c.vec[st_own] = kt.omega;
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            double t0 = x0[2];
-            for (int t = 0; t < T; ++t) { th[t] = t0; t0 = t0 + c.vec[t] * v.dt; }
+        // every lane runs the roll (the rate of stage t from lane 2t's register) and keeps its own stage's
+        // yaw; the lanes of channel 0 publish theirs
+        double t0 = x0[2], mine = x0[2];
+        for (int t = 0; t < T; ++t) {
+            mine = st_own == t ? t0 : mine;
+            t0 = t0 + wave::bcast(kt.omega, 2 * t) * v.dt;
         }
+        if (c.act && ch == 0) th[st_own] = mine;
     }
     __builtin_amdgcn_wave_barrier();
     {
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
                 }
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    gacc = fma(2.0 * Qs[r] * G[r], p[r] - xr[r * W + ts], gacc);
+                    gacc = fma(2.0 * Qs[r] * G[r], p[r] - xw[r * W + ts], gacc);
                     gb[r * kWave + lane] = G[r];
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 gi[r] = 2.0 * Qs[r] * G[r];
-                gacc = fma(gi[r], p[r] - xr[r * W + ts], gacc);
+                gacc = fma(gi[r], p[r] - xw[r * W + ts], gacc);
             }
             // H(i, k) += sum_r gi_r G_r(k) for k <= i < 2 ts; G_r(k) from lane k's registers
             auto cols = [&](int k, auto qn) {
@@ -598,29 +604,40 @@ __global__ __launch_bounds__(kWave) void k_solve_wave(SolveArgs a)
             }
         }
     }
-    double J = wave::wsum(Ju);
+    // The states: every lane runs the roll over the stages (uniform work: LDS reads and ten
+    // multiply-adds per stage), lane t keeps the state after stage t and its weight, and the tracking
+    // cost and the stores are done side by side afterwards.
     {
         double x[3] = {x0[0], x0[1], x0[2]}, qg = 1.0;
+        double mx[3] = {0.0, 0.0, 0.0}, mq = 0.0;
         double *xo = a.x_out + b * 3 * W;
         if (lane < 3) xo[lane * W] = bad ? nan : (lane == 0 ? x[0] : lane == 1 ? x[1] : x[2]);
+        // (plain loads: nothing writes these areas any more, the compiler may fetch stages ahead)
+        const wave::lds_double *dynr = (const wave::lds_double *)dyn, *vecr = (const wave::lds_double *)c.vec, *xwr = (const wave::lds_double *)xw;
         for (int t = 0; t < T; ++t) {
-            volatile wave::lds_double *d = dyn + 11 * t;
-            const double w0 = c.vec[2 * t], w1 = c.vec[2 * t + 1];
+            const wave::lds_double *d = dynr + 11 * t;
+            const double w0 = vecr[2 * t], w1 = vecr[2 * t + 1];
             const double n0 = x[0] + d[0] * x[2] + d[2] * w0 + d[3] * w1 + d[8];
             const double n1 = x[1] + d[1] * x[2] + d[4] * w0 + d[5] * w1 + d[9];
             const double n2 = x[2] + d[6] * w0 + d[7] * w1 + d[10];
             x[0] = n0; x[1] = n1; x[2] = n2;
-            const int ts = t + 1;
-            if (ts < T) qg *= v.q_growth;
+            if (t + 1 < T) qg *= v.q_growth;
+            const bool me = lane == t;
+            mx[0] = me ? n0 : mx[0]; mx[1] = me ? n1 : mx[1]; mx[2] = me ? n2 : mx[2];
+            mq = me ? qg : mq;
+        }
+        if (lane < T) {
+            const int ts = lane + 1;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const double e = xr[r * W + ts] - x[r];
-                const double q = ts < T ? v.Q[r] * qg : v.Qf[r];
-                J = fma(q * e, e, J);
+                const double e = xwr[r * W + ts] - mx[r];
+                const double q = ts < T ? v.Q[r] * mq : v.Qf[r];
+                Ju = fma(q * e, e, Ju);
+                xo[r * W + ts] = bad ? nan : mx[r];
             }
-            if (lane < 3) xo[lane * W + ts] = bad ? nan : (lane == 0 ? x[0] : lane == 1 ? x[1] : x[2]);
         }
     }
+    const double J = wave::wsum(Ju);
     if (lane == 0) {
         a.obj_out[b] = bad ? nan : J;
         a.status_out[b] = status;
